@@ -1,0 +1,192 @@
+/*
+ * lss_hip.h - C ABI of the MI355X (gfx950) Lift-Splat-Shoot camera->BEV path.
+ *
+ * The reference (fircarpediem/LSS2_Multimodal_nu) is pure Python/PyTorch and
+ * has no FFI layer; its boundary for this path is the nn.Module API of
+ * src/model_BEV_TXT.py / src/modules.py / src/tools.py.  This library sits
+ * directly below that boundary: every entry point replaces a run of ATen ops
+ * of the reference (cited per function as "replaces: file:lines", paths
+ * relative to the reference root) and is what a maintainer binds from Python
+ * with ctypes - plain pointers and sizes, no torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     work is enqueued on it, nothing synchronises, nothing allocates;
+ *   - return value: 0 = ok; < 0 = argument check failed (LSS_E_*);
+ *     > 0 = a hipError_t from the launch;
+ *   - functions are re-entrant and keep no global state.
+ *
+ * Index conventions
+ *   point  p    = (((b*N + n)*D + d)*fH + h)*fW + w          0 <= p < P
+ *   pixel  row  = (b*N + n)*fH*fW + h*fW + w
+ *   voxel  v    = ((b*X + ix)*Y + iy)*Z + iz                 0 <= v < B*X*Y*Z
+ *   BEV tensor  = logical (B, Z*C, X, Y), channel = iz*C + c   (ref cat(unbind(2),1))
+ */
+#ifndef LSS_HIP_H_
+#define LSS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSS_ABI_VERSION 1
+
+/* argument-check codes */
+#define LSS_E_NULL (-1)      /* a required pointer is NULL            */
+#define LSS_E_SHAPE (-2)     /* a size is <= 0 or violates a kernel limit */
+#define LSS_E_LAYOUT (-3)    /* unknown layout / dtype enum           */
+#define LSS_E_ALIGN (-4)     /* pointer not aligned as required       */
+#define LSS_E_WORKSPACE (-5) /* workspace too small                   */
+
+/* BEV tensor memory layouts */
+#define LSS_BEV_NCHW_F32 0  /* (B, Z*C, X, Y) contiguous fp32 - the reference's layout */
+#define LSS_BEV_NHWC_F32 1  /* (B, X, Y, Z*C) fp32 = torch channels_last of the same logical tensor */
+#define LSS_BEV_NHWC_BF16 2 /* (B, X, Y, Z*C) bf16 - feeds the MFMA BevEncode convs directly */
+
+/* activation dtypes of the conv path */
+#define LSS_DT_F32 0
+#define LSS_DT_BF16 1
+
+int lss_abi_version(void);
+/* Static string for a return code of this library (never NULL). */
+const char* lss_error_string(int code);
+
+/* ---------------------------------------------------------------------------
+ * K3  frustum points -> voxel ids (exact integer parity with the reference).
+ * replaces: src/model_BEV_TXT.py:59-68 (get_geometry, given the two per-camera
+ *           matrices) + :92 (quantise) + :99-103 (in-box filter) + :106-109.
+ *   frustum        (D,fH,fW,3) fp32  - the state_dict tensor, consumed as is
+ *   inv_post_rots  (B*N,3,3)   fp32  = torch.inverse(post_rots)      [host LAPACK]
+ *   post_trans     (B*N,3)
+ *   combine        (B*N,3,3)   fp32  = rots @ torch.inverse(intrins) [host LAPACK]
+ *   trans          (B*N,3)
+ *   dx, bx         (3) fp32 device   - the module's Parameters
+ *   X,Y,Z                            - nx
+ *   voxel          (P) int32 out: voxel id, or -1 where the reference drops the point
+ *   vox_count      (B*X*Y*Z) int32 in/out, may be NULL: if given, the kernel also
+ *                  histograms (atomicAdd 1 per kept point); caller provides zeros.
+ *   geom           (P,3) fp32 out, may be NULL: the ego-frame points themselves
+ *                  (what `get_geometry` returns, bit-identical to the reference
+ *                  given the same two matrices)
+ * fp32 arithmetic is issued un-contracted in the reference's exact order.
+ */
+int lss_points_to_voxels(const float* frustum, const float* inv_post_rots,
+                         const float* post_trans, const float* combine,
+                         const float* trans, const float* dx, const float* bx,
+                         int B, int N, int D, int fH, int fW, int X, int Y, int Z,
+                         int32_t* voxel, int32_t* vox_count, float* geom, void* stream);
+
+/* API-compat half of K3 for callers that already hold a geometry tensor
+ * (`voxel_pooling(geom_feats, x)`, ref: src/model_BEV_TXT.py:84-109):
+ *   geom (P,3) fp32, P = B * pts_per_sample, sample b owns points [b*pps, (b+1)*pps)
+ */
+int lss_geom_to_voxels(const float* geom, const float* dx, const float* bx, int B,
+                       int pts_per_sample, int X, int Y, int Z, int32_t* voxel,
+                       int32_t* vox_count, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K4  sort-free bucketing of points by voxel (replaces the argsort + gathers of
+ *     src/model_BEV_TXT.py:110-111).
+ *   vox_count (nvox) int32 in/out: per-voxel point counts on entry (from K3),
+ *             all zero again on return (ready for the next call)
+ *   vox_list  (nvox) int2 out: {start, len} of each voxel's slice of point_id
+ *   point_id  (P) int32 out: point ids grouped by voxel; the order inside one
+ *             voxel's slice is unspecified (K5 orders each slice by point id
+ *             before summing, so the BEV sums are run-to-run reproducible)
+ *   cursor    (1) int32 in/out scratch, zero on entry, zero again on return
+ */
+int lss_bucket_points(const int32_t* voxel, int P, int nvox, int32_t* vox_count,
+                      int32_t* vox_list /* nvox*2 */, int32_t* point_id,
+                      int32_t* cursor, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K2  CamEncode: 1x1 depthnet conv + softmax over the D depth logits.
+ * replaces: src/modules.py:82-83 (depthnet, softmax).  The outer product of
+ *           :84 is NOT materialised; the splat kernels form it in registers.
+ *   x      (BN, Cin, HW) fp32 NCHW trunk features (Cin % 16 == 0)
+ *   w      (D+C, Cin) fp32, bias (D+C) fp32 - depthnet.weight / .bias as stored
+ *   depth  (BN, D, HW) fp32 out - softmax probabilities (ref `depth`)
+ *   feat   (BN*HW, C)  fp32 out - context features, pixel-major / channels-last
+ *   math   LSS_DT_F32: f32 MFMA (exact fp32 FMA chains); LSS_DT_BF16: bf16 MFMA
+ */
+int lss_depthnet_softmax_fwd(const float* x, const float* w, const float* bias,
+                             int BN, int Cin, int HW, int D, int C,
+                             float* depth, float* feat, int math, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K5/K6  fused lift + splat: bev[v, c] = sum_{p in voxel v} depth[p] * feat[row(p), c]
+ * replaces: src/modules.py:84 (outer product), src/model_BEV_TXT.py:80,89
+ *           (permute/reshape copy), :110-111 (gathers), src/tools.py:195-200
+ *           (cumsum trick), src/model_BEV_TXT.py:120-124 (zeros, index_put, cat).
+ * Every BEV element is written exactly once (zeros for empty voxels).
+ *   C in {64, 128}; layout = LSS_BEV_*
+ */
+int lss_lift_splat_fwd(const float* depth, const float* feat, const int32_t* vox_list,
+                       const int32_t* point_id, int B, int N, int D, int fH, int fW,
+                       int C, int X, int Y, int Z, void* bev, int layout, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K7  backward of K5/K6 (+ softmax backward), point-stationary gather, no atomics.
+ * replaces: src/tools.py:211-218 (QuickCumsum.backward) + the autograd nodes of
+ *           src/model_BEV_TXT.py:80-121 and src/modules.py:83-84.
+ *   grad_bev   BEV gradient in `layout` (NCHW_F32 or NHWC_F32)
+ *   voxel      (P) int32 from K3
+ *   g_logits   (BN, D+C, HW) fp32 out: gradient w.r.t. the depthnet output
+ *              (softmax backward applied to the first D channels)
+ */
+int lss_lift_splat_bwd(const void* grad_bev, int layout, const int32_t* voxel,
+                       const float* depth, const float* feat, int B, int N, int D,
+                       int fH, int fW, int C, int X, int Y, int Z, float* g_logits,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------
+ * API-compat: segmented sum over rows pre-sorted by rank
+ * replaces: src/tools.py:181-189 / :194-208 (cumsum_trick / QuickCumsum.forward)
+ *   x (K,C) fp32; seg_start (M+1) int32 row offsets of the M equal-rank runs
+ *   y (M,C) fp32 out
+ */
+int lss_segmented_sum(const float* x, const int32_t* seg_start, int M, int C, float* y,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K8  BevEncode convolutions: implicit-GEMM on MFMA, NHWC activations.
+ * replaces: the conv2d / batch_norm / relu / add / interpolate / cat ATen ops of
+ *           src/modules.py:22-27, 118-130 (and torchvision BasicBlock.forward).
+ *
+ * One launch computes
+ *     y = act( scale[co] * conv(in, w)[.., co] + shift[co] + residual )
+ * where `in` is either x itself, or (fused gather) the channel concat
+ *     [ x2 , bilinear_align_corners_upsample(x, up) ]          (ref Up.forward)
+ *   x        (B, H, W, Cx)  NHWC, dtype `dt`
+ *   x2       (B, H*up, W*up, C2) NHWC or NULL (C2 = 0)
+ *   w        packed weights from lss_conv2d_pack_weights
+ *   scale, shift (Cout) fp32 or NULL (=1 / =0): folded eval-mode BatchNorm or bias
+ *   residual (B, Ho, Wo, Cout) dtype `dt` or NULL
+ *   y        (B, Ho, Wo, Cout) dtype `dt`;  Ho = (H*up + 2*pad - KH)/stride + 1
+ *   stats    (2*Cout) fp32 or NULL: if given, per-channel sum and sum of squares
+ *            of the raw conv output are atomically accumulated (training-mode BN)
+ */
+size_t lss_conv2d_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int dt);
+int lss_conv2d_pack_weights(const float* w_oihw, int Cout, int Cin, int KH, int KW,
+                            int dt, void* w_packed, void* stream);
+int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packed,
+                   const float* scale, const float* shift, const void* residual,
+                   void* y, float* stats, int B, int H, int W, int Cx, int C2, int up,
+                   int Cout, int KH, int KW, int stride, int pad, int relu, int dt,
+                   void* stream);
+
+/* Layout / dtype conversion helpers between the reference's NCHW fp32 tensors
+ * and the conv path's NHWC tensors. */
+int lss_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int dt,
+                         void* stream);
+int lss_nhwc_to_nchw_f32(const void* src, float* dst, int B, int C, int H, int W, int dt,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSS_HIP_H_ */

@@ -1,0 +1,80 @@
+"""ctypes binding of csrc/liblss_hip.so (the C ABI declared in include/lss_hip.h).
+
+There is NO fallback: if the library is missing or a kernel reports an error the
+caller gets an exception.  torch is used only to hand over device pointers and
+the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblss_hip.so")
+
+BEV_NCHW_F32, BEV_NHWC_F32, BEV_NHWC_BF16 = 0, 1, 2
+DT_F32, DT_BF16 = 0, 1
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/lss_hip.h
+SIGNATURES = {
+    "lss_abi_version": (_i, []),
+    "lss_error_string": (ctypes.c_char_p, [_i]),
+    "lss_points_to_voxels": (_i, [_vp] * 7 + [_i] * 8 + [_vp, _vp, _vp, _vp]),
+    "lss_geom_to_voxels": (_i, [_vp, _vp, _vp] + [_i] * 5 + [_vp, _vp, _vp]),
+    "lss_bucket_points": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "lss_depthnet_softmax_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "lss_lift_splat_fwd": (_i, [_vp] * 4 + [_i] * 9 + [_vp, _i, _vp]),
+    "lss_lift_splat_bwd": (_i, [_vp, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp, _vp]),
+    "lss_segmented_sum": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "lss_conv2d_packed_weight_bytes": (_sz, [_i] * 5),
+    "lss_conv2d_pack_weights": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "lss_conv2d_fwd": (_i, [_vp] * 8 + [_i] * 13 + [_vp]),
+    "lss_nchw_f32_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "lss_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+class LssNativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LssNativeError(
+                "liblss_hip.so is not built: run `python -m lss2_multimodal_nu_amd.build_native` "
+                "(there is no CPU / eager fallback for the lift-splat path)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the ABI is incomplete
+            fn.restype, fn.argtypes = res, args
+        if L.lss_abi_version() != 1:
+            raise LssNativeError("liblss_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().lss_error_string(code).decode()
+        exc = ValueError if code < 0 else LssNativeError
+        raise exc("%s failed (%d): %s" % (what, code, msg))
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise LssNativeError("expected a GPU tensor, got %s" % t.device)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

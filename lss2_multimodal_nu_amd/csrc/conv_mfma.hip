@@ -1,0 +1,302 @@
+// K8: BevEncode convolutions as implicit GEMM on MFMA, NHWC activations.
+//
+//   out[m, co] = act( scale[co] * sum_{tap, ci} in[pix(m) + tap, ci] * w[tap, co, ci]
+//                     + shift[co] + residual[m, co] )
+// m = (b, oy, ox) output pixel.  `in` is x, or - fused into the operand gather -
+// cat([x2, bilinear_upsample_align_corners(x, up)], channel) of the reference's
+// `Up.forward` (src/modules.py:22-26) and of `up2[0]` (src/modules.py:110-111).
+//
+// Kernel `conv_direct_kernel` (all shapes): 256 threads = 4 waves; the workgroup
+// computes 128 output pixels x 64 output channels, wave w the pixel rows
+// [32w, 32w+32) against both 32-wide channel tiles:
+//   bf16: v_mfma_f32_32x32x16_bf16, A[row r][k = 8h + j]  B[k = 8h + j][col c]
+//   f32 : v_mfma_f32_32x32x2_f32,   A[row r][k = h]       B[k = h][col c]
+// (r = c = lane & 31, h = lane >> 5).  Operand fragments are loaded straight
+// from global memory in 16-B pieces: within a K block every lane half h owns a
+// contiguous run of channels (32 bf16 / 4 f32) and k-step s consumes its s-th
+// piece on BOTH operands, so activations (NHWC) and weights ([tap][co][ci]) keep
+// their natural layouts - only the order of the K summation is permuted.
+#include "lss_common.h"
+
+namespace {
+
+struct ConvArgs {
+  const void* x;
+  const void* x2;
+  const void* w;
+  const float* scale;
+  const float* shift;
+  const void* residual;
+  void* y;
+  float* stats;
+  int B, H, W;  // spatial size of x (low-res source when up > 1)
+  int Cx, C2, up;
+  int Hin, Win;  // H*up, W*up: the conv's input plane
+  int Cin;       // C2 + Cx
+  int Cout, KH, KW, stride, pad;
+  int Ho, Wo, M;
+  int relu;
+  float ry, rx;  // (H-1)/(Hin-1), (W-1)/(Win-1) for the align_corners upsample
+};
+
+template <typename T>
+struct Frag;
+template <>
+struct Frag<unsigned short> {  // bf16: 8 channels per 16-B piece
+  typedef bf16x8 type;
+  static constexpr int PIECE = 8;    // channels per 16-B piece
+  static constexpr int KBLOCK = 64;  // channels per K block (2 halves x 4 pieces)
+};
+template <>
+struct Frag<float> {
+  typedef f32x4 type;
+  static constexpr int PIECE = 4;
+  static constexpr int KBLOCK = 8;  // 2 halves x 1 piece (4 k-steps of 2)
+};
+
+__device__ __forceinline__ f32x4 lerp4(f32x4 a, f32x4 b, float t) {
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = a[i] + t * (b[i] - a[i]);
+  return r;
+}
+
+// 16-B piece (bf16: 8 ch, f32: 4 ch) of pixel (b, iy, ix) of the conv's virtual
+// input, channel offset c (multiple of the piece size, never straddling x2 | x).
+template <typename T, bool FUSED>
+__device__ __forceinline__ uint4 load_in_piece(const ConvArgs& a, int b, int iy, int ix, int c) {
+  if (!FUSED) {
+    const T* p = reinterpret_cast<const T*>(a.x) + (((size_t)b * a.H + iy) * a.W + ix) * a.Cx + c;
+    return *reinterpret_cast<const uint4*>(p);
+  }
+  if (c < a.C2) {
+    const T* p = reinterpret_cast<const T*>(a.x2) + (((size_t)b * a.Hin + iy) * a.Win + ix) * a.C2 + c;
+    return *reinterpret_cast<const uint4*>(p);
+  }
+  c -= a.C2;
+  // nn.Upsample(bilinear, align_corners=True): src = dst * (in-1)/(out-1)
+  const float sy = a.ry * (float)iy, sx = a.rx * (float)ix;
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 + (y0 < a.H - 1 ? 1 : 0), x1 = x0 + (x0 < a.W - 1 ? 1 : 0);
+  const float ly = sy - (float)y0, lx = sx - (float)x0;
+  const T* base = reinterpret_cast<const T*>(a.x) + (size_t)b * a.H * a.W * a.Cx + c;
+  const uint4 q00 = *reinterpret_cast<const uint4*>(base + ((size_t)y0 * a.W + x0) * a.Cx);
+  const uint4 q01 = *reinterpret_cast<const uint4*>(base + ((size_t)y0 * a.W + x1) * a.Cx);
+  const uint4 q10 = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * a.W + x0) * a.Cx);
+  const uint4 q11 = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * a.W + x1) * a.Cx);
+  uint4 out;
+  if (sizeof(T) == 4) {
+    const f32x4 top = lerp4(__builtin_bit_cast(f32x4, q00), __builtin_bit_cast(f32x4, q01), lx);
+    const f32x4 bot = lerp4(__builtin_bit_cast(f32x4, q10), __builtin_bit_cast(f32x4, q11), lx);
+    out = __builtin_bit_cast(uint4, lerp4(top, bot, ly));
+  } else {
+    const unsigned int* u00 = reinterpret_cast<const unsigned int*>(&q00);
+    const unsigned int* u01 = reinterpret_cast<const unsigned int*>(&q01);
+    const unsigned int* u10 = reinterpret_cast<const unsigned int*>(&q10);
+    const unsigned int* u11 = reinterpret_cast<const unsigned int*>(&q11);
+    unsigned int* o = reinterpret_cast<unsigned int*>(&out);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float r[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int sh = hh * 16;
+        const float v00 = lss_bf2f((unsigned short)(u00[i] >> sh)), v01 = lss_bf2f((unsigned short)(u01[i] >> sh));
+        const float v10 = lss_bf2f((unsigned short)(u10[i] >> sh)), v11 = lss_bf2f((unsigned short)(u11[i] >> sh));
+        const float top = v00 + lx * (v01 - v00), bot = v10 + lx * (v11 - v10);
+        r[hh] = top + ly * (bot - top);
+      }
+      o[i] = lss_pack_bf2(r[0], r[1]);
+    }
+  }
+  return out;
+}
+
+template <typename T, bool FUSED>
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
+  constexpr int PIECE = Frag<T>::PIECE;
+  constexpr int KBLOCK = Frag<T>::KBLOCK;
+  constexpr int NPIECE = KBLOCK / 2 / PIECE;  // pieces per lane half per K block (4 / 1)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 128 + wave * 32;
+  const int n0 = blockIdx.y * 64;
+  const int m = m0 + r;
+  const bool m_ok = m < a.M;
+  int b = 0, oy = 0, ox = 0;
+  if (m_ok) {
+    b = m / (a.Ho * a.Wo);
+    const int rem = m - b * (a.Ho * a.Wo);
+    oy = rem / a.Wo;
+    ox = rem - oy * a.Wo;
+  }
+  const T* wbase = reinterpret_cast<const T*>(a.w);
+  const int co0 = n0 + r, co1 = n0 + 32 + r;
+  const bool c0_ok = co0 < a.Cout, c1_ok = co1 < a.Cout;
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+  for (int ky = 0; ky < a.KH; ++ky) {
+    const int iy = oy * a.stride - a.pad + ky;
+    for (int kx = 0; kx < a.KW; ++kx) {
+      const int ix = ox * a.stride - a.pad + kx;
+      const bool in_ok = m_ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+      const int tap = ky * a.KW + kx;
+      const T* w0 = wbase + ((size_t)tap * a.Cout + co0) * a.Cin;
+      const T* w1 = wbase + ((size_t)tap * a.Cout + co1) * a.Cin;
+      for (int cb = 0; cb < a.Cin; cb += KBLOCK) {
+        const int c = cb + h * (KBLOCK / 2);
+        uint4 av[NPIECE], b0[NPIECE], b1[NPIECE];
+#pragma unroll
+        for (int s = 0; s < NPIECE; ++s) {
+          av[s] = make_uint4(0, 0, 0, 0);
+          b0[s] = make_uint4(0, 0, 0, 0);
+          b1[s] = make_uint4(0, 0, 0, 0);
+          if (in_ok) av[s] = load_in_piece<T, FUSED>(a, b, iy, ix, c + s * PIECE);
+          if (c0_ok) b0[s] = *reinterpret_cast<const uint4*>(w0 + c + s * PIECE);
+          if (c1_ok) b1[s] = *reinterpret_cast<const uint4*>(w1 + c + s * PIECE);
+        }
+        if (sizeof(T) == 2) {
+#pragma unroll
+          for (int s = 0; s < NPIECE; ++s) {
+            const bf16x8 fa = __builtin_bit_cast(bf16x8, av[s]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, b0[s]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, b1[s]), acc1, 0, 0, 0);
+          }
+        } else {
+          const f32x4 fa = __builtin_bit_cast(f32x4, av[0]);
+          const f32x4 f0 = __builtin_bit_cast(f32x4, b0[0]);
+          const f32x4 f1 = __builtin_bit_cast(f32x4, b1[0]);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], f0[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], f1[s], acc1, 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // epilogue: D[row = (i&3) + 8*(i>>2) + 4*h][col = r]
+  T* y = reinterpret_cast<T*>(a.y);
+  const T* res = reinterpret_cast<const T*>(a.residual);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int co = nt == 0 ? co0 : co1;
+    const bool cok = nt == 0 ? c0_ok : c1_ok;
+    const float sc = (cok && a.scale) ? a.scale[co] : 1.f;
+    const float sh = (cok && a.shift) ? a.shift[co] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      const int mm = m0 + row;
+      const float raw = nt == 0 ? acc0[i] : acc1[i];
+      if (mm < a.M && cok) {
+        s1 += raw;
+        s2 += raw * raw;
+        float v = raw * sc + sh;
+        const size_t o = (size_t)mm * a.Cout + co;
+        if (res) v += (sizeof(T) == 2) ? lss_bf2f(reinterpret_cast<const unsigned short*>(res)[o])
+                                       : reinterpret_cast<const float*>(res)[o];
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (sizeof(T) == 2) reinterpret_cast<unsigned short*>(y)[o] = lss_f2bf(v);
+        else reinterpret_cast<float*>(y)[o] = v;
+      }
+    }
+    if (a.stats) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0 && cok) {
+        atomicAdd(a.stats + co, s1);
+        atomicAdd(a.stats + a.Cout + co, s2);
+      }
+    }
+  }
+}
+
+// OIHW fp32 -> [tap][co][ci] in T
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, int Cout, int Cin, int KHW,
+                                    T* __restrict__ out) {
+  const size_t n = (size_t)Cout * Cin * KHW;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int ci = e % Cin;
+    const size_t t = e / Cin;
+    const int co = t % Cout;
+    const int tap = t / Cout;
+    const float v = w[((size_t)co * Cin + ci) * KHW + tap];
+    if (sizeof(T) == 2) reinterpret_cast<unsigned short*>(out)[e] = lss_f2bf(v);
+    else reinterpret_cast<float*>(out)[e] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t lss_conv2d_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int dt) {
+  if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
+  return (size_t)Cout * Cin * KH * KW * (dt == LSS_DT_BF16 ? 2 : 4);
+}
+
+extern "C" int lss_conv2d_pack_weights(const float* w_oihw, int Cout, int Cin, int KH, int KW,
+                                       int dt, void* w_packed, void* stream) {
+  LSS_CHECK_PTR(w_oihw); LSS_CHECK_PTR(w_packed);
+  LSS_CHECK_POS(Cout); LSS_CHECK_POS(Cin); LSS_CHECK_POS(KH); LSS_CHECK_POS(KW);
+  const size_t n = (size_t)Cout * Cin * KH * KW;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  if (dt == LSS_DT_BF16)
+    hipLaunchKernelGGL(pack_weights_kernel<unsigned short>, dim3(grid), dim3(256), 0,
+                       lss_stream(stream), w_oihw, Cout, Cin, KH * KW,
+                       reinterpret_cast<unsigned short*>(w_packed));
+  else if (dt == LSS_DT_F32)
+    hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, lss_stream(stream),
+                       w_oihw, Cout, Cin, KH * KW, reinterpret_cast<float*>(w_packed));
+  else
+    return LSS_E_LAYOUT;
+  return lss_launch_status();
+}
+
+extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packed,
+                              const float* scale, const float* shift, const void* residual,
+                              void* y, float* stats, int B, int H, int W, int Cx, int C2, int up,
+                              int Cout, int KH, int KW, int stride, int pad, int relu, int dt,
+                              void* stream) {
+  LSS_CHECK_PTR(x); LSS_CHECK_PTR(w_packed); LSS_CHECK_PTR(y);
+  LSS_CHECK_POS(B); LSS_CHECK_POS(H); LSS_CHECK_POS(W); LSS_CHECK_POS(Cx); LSS_CHECK_POS(Cout);
+  LSS_CHECK_POS(KH); LSS_CHECK_POS(KW); LSS_CHECK_POS(stride); LSS_CHECK_POS(up);
+  if (pad < 0 || C2 < 0) return LSS_E_SHAPE;
+  if (dt != LSS_DT_F32 && dt != LSS_DT_BF16) return LSS_E_LAYOUT;
+  if (C2 > 0 && x2 == nullptr) return LSS_E_NULL;
+  const int kblock = dt == LSS_DT_BF16 ? 64 : 8;
+  // K blocks never straddle the x2 | upsample(x) boundary
+  if (Cx % kblock != 0 || C2 % kblock != 0) return LSS_E_SHAPE;
+  ConvArgs a;
+  a.x = x; a.x2 = x2; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = residual;
+  a.y = y; a.stats = stats;
+  a.B = B; a.H = H; a.W = W; a.Cx = Cx; a.C2 = C2; a.up = up;
+  a.Hin = H * up; a.Win = W * up; a.Cin = Cx + C2;
+  a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+  a.Ho = (a.Hin + 2 * pad - KH) / stride + 1;
+  a.Wo = (a.Win + 2 * pad - KW) / stride + 1;
+  if (a.Ho <= 0 || a.Wo <= 0) return LSS_E_SHAPE;
+  const long long M = (long long)B * a.Ho * a.Wo;
+  if (M >= (1LL << 31)) return LSS_E_SHAPE;
+  a.M = (int)M;
+  a.relu = relu;
+  a.ry = a.Hin > 1 ? (float)(H - 1) / (float)(a.Hin - 1) : 0.f;
+  a.rx = a.Win > 1 ? (float)(W - 1) / (float)(a.Win - 1) : 0.f;
+  const bool fused = (up > 1) || (C2 > 0);
+  dim3 grid(lss_cdiv(M, 128), lss_cdiv(Cout, 64));
+  if (grid.y > 65535) return LSS_E_SHAPE;
+  hipStream_t st = lss_stream(stream);
+  if (dt == LSS_DT_BF16) {
+    if (fused) hipLaunchKernelGGL((conv_direct_kernel<unsigned short, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_direct_kernel<unsigned short, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (fused) hipLaunchKernelGGL((conv_direct_kernel<float, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_direct_kernel<float, false>), grid, dim3(256), 0, st, a);
+  }
+  return lss_launch_status();
+}

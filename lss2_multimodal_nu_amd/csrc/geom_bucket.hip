@@ -1,0 +1,242 @@
+// K3 (frustum point -> voxel id, exact) and K4 (sort-free bucketing).
+//
+// This translation unit MUST be compiled with -ffp-contract=off: the voxel index
+// of a point has to equal the reference's bit for bit, and torch-CPU evaluates
+// every 3x3 * 3 product of get_geometry (ref: src/model_BEV_TXT.py:60,67) as
+// ((m0*p0 + m1*p1) + m2*p2) with each mul/add rounded to fp32.
+// tests/test_build.py greps the ISA of points_to_voxels_kernel for v_fma/v_mac.
+#include "lss_common.h"
+
+namespace {
+
+struct Mat3 {
+  float m[9];
+};
+
+__device__ __forceinline__ void load_mat3(const float* __restrict__ p, Mat3& a) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a.m[i] = p[i];
+}
+
+// ((m0*p0 + m1*p1) + m2*p2), every operation rounded (no contraction in this TU)
+__device__ __forceinline__ float row_dot(const float* m, float p0, float p1, float p2) {
+  float t = __fmul_rn(m[0], p0);
+  t = __fadd_rn(t, __fmul_rn(m[1], p1));
+  return __fadd_rn(t, __fmul_rn(m[2], p2));
+}
+
+// ref :92  ((geom - (bx - dx/2)) / dx).long()   - fp32 sub, true division,
+// truncation toward zero.  x86 maps NaN/inf/huge to INT64_MIN (dropped); here the
+// range test is made on the float quotient so those never reach a conversion:
+//   trunc(q) in [0, n)  <=>  q > -1 && q < n        (q in (-1,0) truncates to 0)
+// ref :99-103 in-box filter, :106-109 rank -> flat voxel id, -1 when dropped.
+__device__ __forceinline__ int quantise_point(float g0, float g1, float g2,
+                                              const float* __restrict__ dx,
+                                              const float* __restrict__ bx, int b, int X, int Y,
+                                              int Z) {
+  const float d0 = dx[0], d1 = dx[1], d2 = dx[2];
+  const float lo0 = __fsub_rn(bx[0], __fmul_rn(d0, 0.5f));
+  const float lo1 = __fsub_rn(bx[1], __fmul_rn(d1, 0.5f));
+  const float lo2 = __fsub_rn(bx[2], __fmul_rn(d2, 0.5f));
+  const float u0 = __fdiv_rn(__fsub_rn(g0, lo0), d0);
+  const float u1 = __fdiv_rn(__fsub_rn(g1, lo1), d1);
+  const float u2 = __fdiv_rn(__fsub_rn(g2, lo2), d2);
+  const bool kept = (u0 > -1.0f) & (u0 < (float)X) & (u1 > -1.0f) & (u1 < (float)Y) &
+                    (u2 > -1.0f) & (u2 < (float)Z);
+  if (!kept) return -1;
+  const int ix = (int)u0, iy = (int)u1, iz = (int)u2;  // v_cvt_i32_f32 truncates
+  return ((b * X + ix) * Y + iy) * Z + iz;
+}
+
+// grid = (ceil(D*fH*fW / 256), B*N); one thread per frustum point of one camera
+__global__ __launch_bounds__(256) void points_to_voxels_kernel(
+    const float* __restrict__ frustum, const float* __restrict__ inv_post_rots,
+    const float* __restrict__ post_trans, const float* __restrict__ combine,
+    const float* __restrict__ trans, const float* __restrict__ dx,
+    const float* __restrict__ bx, int Ncam, int DHW, int X, int Y, int Z,
+    int32_t* __restrict__ voxel, int32_t* __restrict__ vox_count, float* __restrict__ geom) {
+  const int bn = blockIdx.y;
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= DHW) return;
+  Mat3 ipr, cmb;
+  load_mat3(inv_post_rots + bn * 9, ipr);  // block-uniform -> scalar loads
+  load_mat3(combine + bn * 9, cmb);
+  const float pt0 = post_trans[bn * 3 + 0], pt1 = post_trans[bn * 3 + 1], pt2 = post_trans[bn * 3 + 2];
+  const float t0 = trans[bn * 3 + 0], t1 = trans[bn * 3 + 1], t2 = trans[bn * 3 + 2];
+
+  // ref :59  points = frustum - post_trans
+  const float p0 = __fsub_rn(frustum[f * 3 + 0], pt0);
+  const float p1 = __fsub_rn(frustum[f * 3 + 1], pt1);
+  const float p2 = __fsub_rn(frustum[f * 3 + 2], pt2);
+  // ref :60  inv(post_rots) @ points
+  const float q0 = row_dot(ipr.m + 0, p0, p1, p2);
+  const float q1 = row_dot(ipr.m + 3, p0, p1, p2);
+  const float q2 = row_dot(ipr.m + 6, p0, p1, p2);
+  // ref :63-65  (x*z, y*z, z)
+  const float r0 = __fmul_rn(q0, q2);
+  const float r1 = __fmul_rn(q1, q2);
+  // ref :67-68  combine @ points + trans
+  const float g0 = __fadd_rn(row_dot(cmb.m + 0, r0, r1, q2), t0);
+  const float g1 = __fadd_rn(row_dot(cmb.m + 3, r0, r1, q2), t1);
+  const float g2 = __fadd_rn(row_dot(cmb.m + 6, r0, r1, q2), t2);
+
+  if (geom) {
+    float* gp = geom + ((size_t)bn * DHW + f) * 3;
+    gp[0] = g0; gp[1] = g1; gp[2] = g2;
+  }
+  const int v = quantise_point(g0, g1, g2, dx, bx, bn / Ncam, X, Y, Z);
+  if (v >= 0 && vox_count) atomicAdd(vox_count + v, 1);
+  voxel[(size_t)bn * DHW + f] = v;
+}
+
+__global__ __launch_bounds__(256) void geom_to_voxels_kernel(const float* __restrict__ geom,
+                                                             const float* __restrict__ dx,
+                                                             const float* __restrict__ bx, int P,
+                                                             int pps, int X, int Y, int Z,
+                                                             int32_t* __restrict__ voxel,
+                                                             int32_t* __restrict__ vox_count) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int v = quantise_point(geom[(size_t)p * 3], geom[(size_t)p * 3 + 1], geom[(size_t)p * 3 + 2],
+                               dx, bx, p / pps, X, Y, Z);
+  if (v >= 0 && vox_count) atomicAdd(vox_count + v, 1);
+  voxel[p] = v;
+}
+
+// One wave per 64 voxels: wave-scan the counts, reserve the tile's slice of
+// point_id with ONE atomic on the cursor (tile order in point_id is arbitrary,
+// every voxel's slice is contiguous).
+__global__ __launch_bounds__(256) void bucket_alloc_kernel(const int32_t* __restrict__ vox_count,
+                                                           int nvox, int32_t* __restrict__ vox_list,
+                                                           int32_t* __restrict__ cursor) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int v = wave * 64 + lane;
+  const int c = (v < nvox) ? vox_count[v] : 0;
+  int incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  const int total = __shfl(incl, 63, 64);
+  int base = 0;
+  if (total > 0) {
+    if (lane == 0) base = atomicAdd(cursor, total);
+    base = __shfl(base, 0, 64);
+  }
+  if (v < nvox) {
+    vox_list[2 * v + 0] = base + incl - c;
+    vox_list[2 * v + 1] = c;
+  }
+}
+
+// One thread per point: take a slot of the voxel's slice by counting the voxel's
+// counter back down to zero (so vox_count is all-zero again for the next call).
+__global__ __launch_bounds__(256) void bucket_fill_kernel(const int32_t* __restrict__ voxel, int P,
+                                                          int32_t* __restrict__ vox_count,
+                                                          const int32_t* __restrict__ vox_list,
+                                                          int32_t* __restrict__ point_id,
+                                                          int32_t* __restrict__ cursor) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p == 0) *cursor = 0;  // alloc (previous kernel on the stream) is done with it
+  if (p >= P) return;
+  const int v = voxel[p];
+  if (v < 0) return;
+  const int slot = atomicSub(vox_count + v, 1) - 1;
+  point_id[vox_list[2 * v] + slot] = p;
+}
+
+// API-compat segmented sum (QuickCumsum.forward): one wave per run, lane = channel.
+__global__ __launch_bounds__(256) void segmented_sum_kernel(const float* __restrict__ x,
+                                                            const int32_t* __restrict__ seg_start,
+                                                            int M, int C, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int m = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (m >= M) return;
+  const int s = seg_start[m], e = seg_start[m + 1];
+  for (int c = lane; c < C; c += 64) {
+    float acc = 0.f;
+    for (int r = s; r < e; ++r) acc += x[(size_t)r * C + c];
+    y[(size_t)m * C + c] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int lss_points_to_voxels(const float* frustum, const float* inv_post_rots,
+                                    const float* post_trans, const float* combine,
+                                    const float* trans, const float* dx, const float* bx, int B,
+                                    int N, int D, int fH, int fW, int X, int Y, int Z,
+                                    int32_t* voxel, int32_t* vox_count, float* geom, void* stream) {
+  LSS_CHECK_PTR(frustum); LSS_CHECK_PTR(inv_post_rots); LSS_CHECK_PTR(post_trans);
+  LSS_CHECK_PTR(combine); LSS_CHECK_PTR(trans); LSS_CHECK_PTR(dx); LSS_CHECK_PTR(bx);
+  LSS_CHECK_PTR(voxel);
+  LSS_CHECK_POS(B); LSS_CHECK_POS(N); LSS_CHECK_POS(D); LSS_CHECK_POS(fH); LSS_CHECK_POS(fW);
+  LSS_CHECK_POS(X); LSS_CHECK_POS(Y); LSS_CHECK_POS(Z);
+  const long long DHW = (long long)D * fH * fW;
+  const long long nvox = (long long)B * X * Y * Z;
+  if (DHW * B * N >= (1LL << 31) || nvox >= (1LL << 31) || (long long)B * N > 65535 ||
+      X >= (1 << 24) || Y >= (1 << 24) || Z >= (1 << 24))
+    return LSS_E_SHAPE;
+  dim3 grid(lss_cdiv(DHW, 256), B * N);
+  hipLaunchKernelGGL(points_to_voxels_kernel, grid, dim3(256), 0, lss_stream(stream), frustum,
+                     inv_post_rots, post_trans, combine, trans, dx, bx, N, (int)DHW, X, Y, Z,
+                     voxel, vox_count, geom);
+  return lss_launch_status();
+}
+
+extern "C" int lss_geom_to_voxels(const float* geom, const float* dx, const float* bx, int B,
+                                  int pts_per_sample, int X, int Y, int Z, int32_t* voxel,
+                                  int32_t* vox_count, void* stream) {
+  LSS_CHECK_PTR(geom); LSS_CHECK_PTR(dx); LSS_CHECK_PTR(bx); LSS_CHECK_PTR(voxel);
+  LSS_CHECK_POS(B); LSS_CHECK_POS(pts_per_sample); LSS_CHECK_POS(X); LSS_CHECK_POS(Y); LSS_CHECK_POS(Z);
+  const long long P = (long long)B * pts_per_sample;
+  if (P >= (1LL << 31) || (long long)B * X * Y * Z >= (1LL << 31) || X >= (1 << 24) ||
+      Y >= (1 << 24) || Z >= (1 << 24))
+    return LSS_E_SHAPE;
+  hipLaunchKernelGGL(geom_to_voxels_kernel, dim3(lss_cdiv(P, 256)), dim3(256), 0,
+                     lss_stream(stream), geom, dx, bx, (int)P, pts_per_sample, X, Y, Z, voxel,
+                     vox_count);
+  return lss_launch_status();
+}
+
+extern "C" int lss_bucket_points(const int32_t* voxel, int P, int nvox, int32_t* vox_count,
+                                 int32_t* vox_list, int32_t* point_id, int32_t* cursor,
+                                 void* stream) {
+  LSS_CHECK_PTR(voxel); LSS_CHECK_PTR(vox_count); LSS_CHECK_PTR(vox_list);
+  LSS_CHECK_PTR(point_id); LSS_CHECK_PTR(cursor);
+  LSS_CHECK_POS(P); LSS_CHECK_POS(nvox);
+  hipLaunchKernelGGL(bucket_alloc_kernel, dim3(lss_cdiv(nvox, 256)), dim3(256), 0,
+                     lss_stream(stream), vox_count, nvox, vox_list, cursor);
+  hipLaunchKernelGGL(bucket_fill_kernel, dim3(lss_cdiv(P, 256)), dim3(256), 0,
+                     lss_stream(stream), voxel, P, vox_count, vox_list, point_id, cursor);
+  return lss_launch_status();
+}
+
+extern "C" int lss_segmented_sum(const float* x, const int32_t* seg_start, int M, int C, float* y,
+                                 void* stream) {
+  LSS_CHECK_PTR(x); LSS_CHECK_PTR(seg_start); LSS_CHECK_PTR(y);
+  LSS_CHECK_POS(C);
+  if (M < 0) return LSS_E_SHAPE;
+  if (M == 0) return 0;
+  hipLaunchKernelGGL(segmented_sum_kernel, dim3(lss_cdiv((long long)M * 64, 256)), dim3(256), 0,
+                     lss_stream(stream), x, seg_start, M, C, y);
+  return lss_launch_status();
+}
+
+extern "C" int lss_abi_version(void) { return LSS_ABI_VERSION; }
+
+extern "C" const char* lss_error_string(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case LSS_E_NULL: return "lss: required pointer is NULL";
+    case LSS_E_SHAPE: return "lss: size out of range for this kernel";
+    case LSS_E_LAYOUT: return "lss: unknown layout or dtype";
+    case LSS_E_ALIGN: return "lss: pointer not sufficiently aligned";
+    case LSS_E_WORKSPACE: return "lss: workspace too small";
+    default: break;
+  }
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "lss: unknown error";
+}

@@ -1,0 +1,221 @@
+"""Tensor-level wrappers over the C ABI (include/lss_hip.h).
+
+Each function validates shapes/dtypes on the host (a mis-shaped operand must
+never reach a kernel), allocates outputs with torch, and enqueues the kernel on
+torch's current HIP stream.  No CPU / eager fallbacks exist here.
+"""
+import torch
+
+from . import _native as N
+from ._native import BEV_NCHW_F32, BEV_NHWC_BF16, BEV_NHWC_F32, DT_BF16, DT_F32  # noqa: F401
+
+
+def _f32c(t, name, shape=None):
+    if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+        raise ValueError("%s must be a contiguous fp32 GPU tensor (got %s %s contiguous=%s)"
+                         % (name, t.dtype, t.device, t.is_contiguous()))
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return t
+
+
+class SplatWorkspace:
+    """Index buffers of one (B,N,D,fH,fW | X,Y,Z) problem, reused across steps.
+
+    vox_count and cursor obey the K4 contract: zero on entry, zero on return, so
+    they are zero-filled exactly once, here."""
+
+    def __init__(self, P, nvox, device):
+        self.P, self.nvox = P, nvox
+        self.voxel = torch.empty(P, dtype=torch.int32, device=device)
+        self.vox_count = torch.zeros(nvox, dtype=torch.int32, device=device)
+        self.vox_list = torch.empty(nvox, 2, dtype=torch.int32, device=device)
+        self.point_id = torch.empty(P, dtype=torch.int32, device=device)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def points_to_voxels(frustum, inv_post_rots, post_trans, combine, trans, dx, bx, nx, ws,
+                     want_geom=False, histogram=True):
+    """K3.  frustum (D,fH,fW,3); per-camera tensors (B,N,3,3)/(B,N,3); nx = (X,Y,Z) ints.
+    Fills ws.voxel (+ ws.vox_count histogram); returns geom (B,N,D,fH,fW,3) or None."""
+    D, fH, fW, _ = frustum.shape
+    B, Ncam = inv_post_rots.shape[:2]
+    X, Y, Z = nx
+    _f32c(frustum, "frustum", (D, fH, fW, 3))
+    _f32c(inv_post_rots, "inv_post_rots", (B, Ncam, 3, 3))
+    _f32c(combine, "combine", (B, Ncam, 3, 3))
+    _f32c(post_trans, "post_trans", (B, Ncam, 3))
+    _f32c(trans, "trans", (B, Ncam, 3))
+    _f32c(dx, "dx", (3,))
+    _f32c(bx, "bx", (3,))
+    P = B * Ncam * D * fH * fW
+    if ws.P != P or ws.nvox != B * X * Y * Z:
+        raise ValueError("workspace sized for P=%d nvox=%d, problem has P=%d nvox=%d"
+                         % (ws.P, ws.nvox, P, B * X * Y * Z))
+    geom = torch.empty(B, Ncam, D, fH, fW, 3, dtype=torch.float32, device=frustum.device) if want_geom else None
+    N.check(N.lib().lss_points_to_voxels(
+        N.ptr(frustum), N.ptr(inv_post_rots), N.ptr(post_trans), N.ptr(combine), N.ptr(trans),
+        N.ptr(dx), N.ptr(bx), B, Ncam, D, fH, fW, X, Y, Z, N.ptr(ws.voxel),
+        N.ptr(ws.vox_count) if histogram else None, N.ptr(geom), N.stream()), "lss_points_to_voxels")
+    return geom
+
+
+def geom_to_voxels(geom, dx, bx, nx, B, ws, histogram=True):
+    """API-compat half of K3: geom (..., 3) fp32 with B samples of equal point count."""
+    _f32c(geom, "geom")
+    P = geom.numel() // 3
+    X, Y, Z = nx
+    if geom.shape[-1] != 3 or P % B != 0 or ws.P != P or ws.nvox != B * X * Y * Z:
+        raise ValueError("geom / workspace shape mismatch")
+    N.check(N.lib().lss_geom_to_voxels(N.ptr(geom), N.ptr(_f32c(dx, "dx", (3,))), N.ptr(_f32c(bx, "bx", (3,))),
+                                       B, P // B, X, Y, Z, N.ptr(ws.voxel),
+                                       N.ptr(ws.vox_count) if histogram else None, N.stream()),
+            "lss_geom_to_voxels")
+
+
+def bucket_points(ws):
+    """K4 on a workspace whose voxel/vox_count were filled by K3."""
+    N.check(N.lib().lss_bucket_points(N.ptr(ws.voxel), ws.P, ws.nvox, N.ptr(ws.vox_count),
+                                      N.ptr(ws.vox_list), N.ptr(ws.point_id), N.ptr(ws.cursor),
+                                      N.stream()), "lss_bucket_points")
+
+
+def depthnet_softmax(x, weight, bias, D, C, math=DT_F32):
+    """K2.  x (BN,Cin,fH,fW) fp32 NCHW; weight (D+C,Cin,1,1) or (D+C,Cin); bias (D+C).
+    Returns depth (BN,D,fH,fW) and feat (BN,fH,fW,C) (channels-last rows)."""
+    BN, Cin, fH, fW = x.shape
+    _f32c(x, "x")
+    w2 = weight.reshape(weight.shape[0], -1)
+    _f32c(w2, "depthnet.weight", (D + C, Cin))
+    _f32c(bias, "depthnet.bias", (D + C,))
+    depth = torch.empty(BN, D, fH, fW, dtype=torch.float32, device=x.device)
+    feat = torch.empty(BN, fH, fW, C, dtype=torch.float32, device=x.device)
+    N.check(N.lib().lss_depthnet_softmax_fwd(N.ptr(x), N.ptr(w2), N.ptr(bias), BN, Cin, fH * fW, D, C,
+                                             N.ptr(depth), N.ptr(feat), math, N.stream()),
+            "lss_depthnet_softmax_fwd")
+    return depth, feat
+
+
+def lift_splat_fwd(depth, feat, ws, dims, nx, layout=BEV_NCHW_F32):
+    """K5/K6.  dims = (B,N,D,fH,fW,C).  Returns the BEV tensor with LOGICAL shape
+    (B, Z*C, X, Y): contiguous for NCHW_F32, channels_last strides for NHWC_*."""
+    B, Ncam, D, fH, fW, C = dims
+    X, Y, Z = nx
+    _f32c(depth, "depth")
+    _f32c(feat, "feat")
+    if depth.numel() != B * Ncam * D * fH * fW or feat.numel() != B * Ncam * fH * fW * C:
+        raise ValueError("depth/feat size does not match dims %s" % (dims,))
+    if ws.P != depth.numel() or ws.nvox != B * X * Y * Z:
+        raise ValueError("workspace does not match dims")
+    dev = depth.device
+    if layout == BEV_NCHW_F32:
+        bev = torch.empty(B, Z * C, X, Y, dtype=torch.float32, device=dev)
+        out = bev
+    else:
+        dt = torch.float32 if layout == BEV_NHWC_F32 else torch.bfloat16
+        bev = torch.empty(B, X, Y, Z * C, dtype=dt, device=dev)
+        out = bev.permute(0, 3, 1, 2)
+    N.check(N.lib().lss_lift_splat_fwd(N.ptr(depth), N.ptr(feat), N.ptr(ws.vox_list), N.ptr(ws.point_id),
+                                       B, Ncam, D, fH, fW, C, X, Y, Z, N.ptr(bev), layout, N.stream()),
+            "lss_lift_splat_fwd")
+    return out
+
+
+def lift_splat_bwd(grad_bev, voxel, depth, feat, dims, nx):
+    """K7.  grad_bev logical (B, Z*C, X, Y), contiguous or channels_last fp32.
+    Returns g_logits (BN, D+C, fH, fW)."""
+    B, Ncam, D, fH, fW, C = dims
+    X, Y, Z = nx
+    if grad_bev.dtype != torch.float32 or tuple(grad_bev.shape) != (B, Z * C, X, Y):
+        raise ValueError("grad_bev must be fp32 (B, Z*C, X, Y)")
+    if grad_bev.is_contiguous():
+        layout = BEV_NCHW_F32
+    elif grad_bev.is_contiguous(memory_format=torch.channels_last):
+        layout = BEV_NHWC_F32
+    else:
+        grad_bev = grad_bev.contiguous()
+        layout = BEV_NCHW_F32
+    g_logits = torch.empty(B * Ncam, D + C, fH, fW, dtype=torch.float32, device=grad_bev.device)
+    N.check(N.lib().lss_lift_splat_bwd(N.ptr(grad_bev), layout, N.ptr(voxel), N.ptr(depth), N.ptr(feat),
+                                       B, Ncam, D, fH, fW, C, X, Y, Z, N.ptr(g_logits), N.stream()),
+            "lss_lift_splat_bwd")
+    return g_logits
+
+
+def segmented_sum(x, seg_start):
+    """x (K,C) fp32, seg_start (M+1) int32 -> (M,C)."""
+    _f32c(x, "x")
+    M = seg_start.numel() - 1
+    y = torch.empty(M, x.shape[1], dtype=torch.float32, device=x.device)
+    if M > 0:
+        N.check(N.lib().lss_segmented_sum(N.ptr(x), N.ptr(seg_start), M, x.shape[1], N.ptr(y), N.stream()),
+                "lss_segmented_sum")
+    return y
+
+
+_TORCH_DT = {DT_F32: torch.float32, DT_BF16: torch.bfloat16}
+
+
+def pack_conv_weight(w_oihw, dt):
+    """OIHW fp32 -> the conv kernels' [tap][Cout][Cin] layout in `dt`."""
+    Cout, Cin, KH, KW = w_oihw.shape
+    _f32c(w_oihw, "conv weight")
+    out = torch.empty(KH * KW, Cout, Cin, dtype=_TORCH_DT[dt], device=w_oihw.device)
+    nbytes = N.lib().lss_conv2d_packed_weight_bytes(Cout, Cin, KH, KW, dt)
+    assert nbytes == out.numel() * out.element_size()
+    N.check(N.lib().lss_conv2d_pack_weights(N.ptr(w_oihw), Cout, Cin, KH, KW, dt, N.ptr(out), N.stream()),
+            "lss_conv2d_pack_weights")
+    return out
+
+
+def conv2d_nhwc(x, w_packed, ksize, stride, pad, scale=None, shift=None, residual=None, relu=False,
+                x2=None, up=1, stats=None, dt=DT_BF16):
+    """K8.  x (B,H,W,Cx) NHWC in `dt`; x2 (B,H*up,W*up,C2) optional skip tensor
+    (conv input = cat([x2, upsample(x, up)])).  Returns y (B,Ho,Wo,Cout) in `dt`."""
+    tdt = _TORCH_DT[dt]
+    B, H, W, Cx = x.shape
+    KH, KW = ksize
+    taps, Cout, Cin = w_packed.shape
+    C2 = 0
+    if x.dtype != tdt or not x.is_contiguous() or w_packed.dtype != tdt or not w_packed.is_contiguous():
+        raise ValueError("conv operands must be contiguous %s" % tdt)
+    if x2 is not None:
+        if x2.dtype != tdt or not x2.is_contiguous() or tuple(x2.shape[:3]) != (B, H * up, W * up):
+            raise ValueError("x2 must be contiguous %s of shape (B,H*up,W*up,C2)" % tdt)
+        C2 = x2.shape[3]
+    if taps != KH * KW or Cin != Cx + C2:
+        raise ValueError("packed weight %s does not match Cin=%d taps=%d" % (tuple(w_packed.shape), Cx + C2, KH * KW))
+    Ho = (H * up + 2 * pad - KH) // stride + 1
+    Wo = (W * up + 2 * pad - KW) // stride + 1
+    y = torch.empty(B, Ho, Wo, Cout, dtype=tdt, device=x.device)
+    for name, t in (("scale", scale), ("shift", shift)):
+        if t is not None:
+            _f32c(t, name, (Cout,))
+    if residual is not None and (residual.dtype != tdt or tuple(residual.shape) != tuple(y.shape)
+                                 or not residual.is_contiguous()):
+        raise ValueError("residual must match the output")
+    if stats is not None:
+        _f32c(stats, "stats", (2 * Cout,))
+    N.check(N.lib().lss_conv2d_fwd(N.ptr(x), N.ptr(x2), N.ptr(w_packed), N.ptr(scale), N.ptr(shift),
+                                   N.ptr(residual), N.ptr(y), N.ptr(stats), B, H, W, Cx, C2, up, Cout,
+                                   KH, KW, stride, pad, 1 if relu else 0, dt, N.stream()), "lss_conv2d_fwd")
+    return y
+
+
+def nchw_to_nhwc(x, dt):
+    """(B,C,H,W) fp32 contiguous -> (B,H,W,C) in dt."""
+    _f32c(x, "x")
+    B, C, H, W = x.shape
+    y = torch.empty(B, H, W, C, dtype=_TORCH_DT[dt], device=x.device)
+    N.check(N.lib().lss_nchw_f32_to_nhwc(N.ptr(x), N.ptr(y), B, C, H, W, dt, N.stream()), "lss_nchw_f32_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x, dt):
+    """(B,H,W,C) in dt -> (B,C,H,W) fp32 contiguous."""
+    if x.dtype != _TORCH_DT[dt] or not x.is_contiguous():
+        raise ValueError("x must be contiguous %s" % _TORCH_DT[dt])
+    B, H, W, C = x.shape
+    y = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+    N.check(N.lib().lss_nhwc_to_nchw_f32(N.ptr(x), N.ptr(y), B, C, H, W, dt, N.stream()), "lss_nhwc_to_nchw_f32")
+    return y

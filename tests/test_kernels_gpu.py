@@ -1,0 +1,325 @@
+"""Parity of every HIP kernel (through the C ABI) against the CPU oracle and the
+golden fixtures captured from the reference.  Run with `-m gpu` on an MI355X."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bev_oracle as bo  # noqa: E402
+from oracle import lss_oracle as lo  # noqa: E402
+
+GRID_DEFAULT = dict(xbound=[-50.0, 50.0, 0.5], ybound=[-50.0, 50.0, 0.5],
+                    zbound=[-10.0, 10.0, 20.0], dbound=[4.0, 45.0, 1.0])
+GRID_HIRES = dict(xbound=[-50.0, 50.0, 0.25], ybound=[-50.0, 50.0, 0.25],
+                  zbound=[-10.0, 10.0, 20.0], dbound=[1.0, 61.0, 1.0])
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from lss2_multimodal_nu_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def run_k3(ops, g, frustum, dxbxnx, want_geom=True):
+    dx, bx, nx = dxbxnx
+    B, Ncam = g["trans"].shape[:2]
+    D, fH, fW, _ = frustum.shape
+    X, Y, Z = [int(v) for v in nx]
+    ws = ops.SplatWorkspace(B * Ncam * D * fH * fW, B * X * Y * Z, "cuda")
+    geom = ops.points_to_voxels(frustum.cuda(), dev(g["inv_post_rots"]), dev(g["post_trans"]),
+                                dev(g["combine"]), dev(g["trans"]), dx.cuda(), bx.cuda(), (X, Y, Z), ws,
+                                want_geom=want_geom)
+    return ws, geom
+
+
+G3 = ["g3_val_b1_s0", "g3_val_b1_s1", "g3_val_b1_s2", "g3_train_b1_s0", "g3_train_b1_s1",
+      "g3_train_b1_s2", "g3_randn_b1_s0", "g3_randn_b1_s1", "g3_train_b4_s0", "g3_hires_b2_s0"]
+
+
+@pytest.mark.parametrize("name", G3)
+def test_k3_voxel_ids_exact(ops, golden, name):
+    """Voxel ids and ego-frame points are BIT-EXACT vs the reference (fixtures
+    hold the reference's own outputs; Z = 1 so voxel id == cell id)."""
+    g = golden(name)
+    hires = "hires" in name
+    gc = GRID_HIRES if hires else GRID_DEFAULT
+    fr = lo.create_frustum((256, 704) if hires else (128, 352), 16, gc["dbound"])
+    dxbxnx = lo.gen_dx_bx(gc["xbound"], gc["ybound"], gc["zbound"])
+    ws, geom = run_k3(ops, g, fr, dxbxnx)
+    voxel = ws.voxel.cpu().numpy()
+    assert sha(geom.cpu().numpy()) == str(g["geom_sha256"])
+    assert sha(voxel) == str(g["cell_sha256"])
+    assert int((voxel >= 0).sum()) == int(g["n_kept"])
+    if "cell" in g:
+        assert np.array_equal(voxel, g["cell"])
+    # histogram == bincount of kept ids
+    cnt = ws.vox_count.cpu().numpy()
+    ref = np.bincount(voxel[voxel >= 0], minlength=cnt.size)
+    assert np.array_equal(cnt, ref)
+
+
+@pytest.mark.parametrize("name", ["g3_train_b1_s0", "g3_train_b4_s0", "g3_randn_b1_s0"])
+def test_k4_bucketing(ops, golden, name):
+    g = golden(name)
+    fr = lo.create_frustum((128, 352), 16, GRID_DEFAULT["dbound"])
+    dxbxnx = lo.gen_dx_bx(GRID_DEFAULT["xbound"], GRID_DEFAULT["ybound"], GRID_DEFAULT["zbound"])
+    ws, _ = run_k3(ops, g, fr, dxbxnx, want_geom=False)
+    for rep in range(2):  # second pass checks the zero-on-return contract
+        if rep == 1:
+            ops.points_to_voxels(fr.cuda(), dev(g["inv_post_rots"]), dev(g["post_trans"]), dev(g["combine"]),
+                                 dev(g["trans"]), dxbxnx[0].cuda(), dxbxnx[1].cuda(),
+                                 tuple(int(v) for v in dxbxnx[2]), ws)
+        ops.bucket_points(ws)
+        torch.cuda.synchronize()
+        assert int(ws.vox_count.abs().sum()) == 0 and int(ws.cursor[0]) == 0
+        voxel = ws.voxel.cpu().numpy()
+        vl = ws.vox_list.cpu().numpy()
+        pid = ws.point_id.cpu().numpy()
+        kept = np.flatnonzero(voxel >= 0)
+        cnt = np.bincount(voxel[kept], minlength=ws.nvox)
+        assert np.array_equal(vl[:, 1], cnt)
+        occ = np.flatnonzero(cnt)
+        # slices are disjoint and tile [0, K)
+        order = np.argsort(vl[occ, 0])
+        starts, lens = vl[occ, 0][order], vl[occ, 1][order]
+        assert starts[0] == 0 and np.array_equal(starts[1:], np.cumsum(lens)[:-1])
+        assert starts[-1] + lens[-1] == kept.size
+        # every slice holds exactly the voxel's points
+        got_vox = np.repeat(occ[order], lens)
+        assert np.array_equal(voxel[pid[:kept.size]], got_vox)
+        assert np.array_equal(np.sort(pid[:kept.size]), kept)
+
+
+def _depthnet_ref(x, w, b, D, C):
+    depth, _ = lo.cam_encode_torch(x, w, b, D, C)
+    y = torch.nn.functional.conv2d(x, w, b)
+    return depth, y[:, D:D + C].permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("shape", [(2, 512, 2, 3, 41, 64), (24, 512, 8, 22, 41, 64), (3, 512, 16, 44, 60, 64),
+                                   (2, 768, 5, 7, 41, 128), (1, 128, 3, 3, 5, 64)])
+def test_k2_depthnet_softmax(ops, golden, shape):
+    BN, Cin, fH, fW, D, C = shape
+    if shape[:4] == (2, 512, 2, 3):
+        g = golden("g6_camencode")
+        x, w, b = torch.from_numpy(g["x"]), torch.from_numpy(g["weight"]), torch.from_numpy(g["bias"])
+    else:
+        gen = torch.Generator().manual_seed(BN + fH)
+        x = torch.randn(BN, Cin, fH, fW, generator=gen)
+        w = torch.randn(D + C, Cin, 1, 1, generator=gen) * Cin ** -0.5
+        b = torch.randn(D + C, generator=gen) * 0.1
+    dref, fref = _depthnet_ref(x, w, b, D, C)
+    depth, feat = ops.depthnet_softmax(x.cuda(), w.cuda(), b.cuda(), D, C, ops.DT_F32)
+    # fp32 MFMA = exact fp32 FMA chains: only the summation order differs from oneDNN
+    np.testing.assert_allclose(depth.cpu().numpy(), dref.numpy(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(feat.cpu().numpy(), fref.numpy(), rtol=1e-4, atol=1e-5)
+    if shape[:4] == (2, 512, 2, 3):
+        np.testing.assert_allclose(depth.cpu().numpy(), g["depth"], rtol=2e-5, atol=1e-7)
+        lifted = depth.unsqueeze(1).cpu() * feat.permute(0, 3, 1, 2).unsqueeze(2).cpu()
+        np.testing.assert_allclose(lifted.numpy(), g["lifted"], rtol=1e-4, atol=1e-6)
+    if Cin % 128 == 0:
+        d16, f16 = ops.depthnet_softmax(x.cuda(), w.cuda(), b.cuda(), D, C, ops.DT_BF16)
+        # bf16 operands: ~2^-9 relative per product, K = Cin
+        assert float((d16.cpu() - dref).abs().max()) < 2e-2
+        assert float((f16.cpu() - fref).abs().max()) < 6e-2 * float(fref.abs().max())
+        np.testing.assert_allclose(d16.sum(1).cpu().numpy(), 1.0, rtol=1e-5)
+
+
+def _small(golden, name):
+    g = golden(name)
+    B, N, D, fH, fW, C = [int(v) for v in g["dims"]]
+    xb, yb, zb, db = g["bounds"].tolist()
+    return g, (B, N, D, fH, fW, C), lo.gen_dx_bx(xb, yb, zb), db
+
+
+LAYOUTS = [0, 1, 2]
+
+
+@pytest.mark.parametrize("name", ["g4_small_c64", "g4_small_z2"])
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_k5_lift_splat_small_vs_reference(ops, golden, name, layout):
+    """depthnet -> K3 -> K4 -> K5 on the small fixtures: BEV vs the REFERENCE's
+    voxel_pooling output (1e-3 rule of SURVEY 8a-7) and vs the fp64 direct sum."""
+    g, dims, (dx, bx, nx), db = _small(golden, name)
+    B, N, D, fH, fW, C = dims
+    X, Y, Z = [int(v) for v in nx]
+    fr = torch.from_numpy(g["frustum"])
+    ws, geom = run_k3(ops, g, fr, (dx, bx, nx))
+    assert np.array_equal(geom.cpu().numpy(), g["geom"])
+    vox_ref = np.where(g["cell"] >= 0, g["cell"] * Z + g["iz"], -1)
+    assert np.array_equal(ws.voxel.cpu().numpy(), vox_ref)
+    ops.bucket_points(ws)
+    depth, feat = ops.depthnet_softmax(dev(g["feat_in"]), dev(g["depthnet_weight"]), dev(g["depthnet_bias"]), D, C)
+    np.testing.assert_allclose(depth.cpu().numpy(), g["depth"], rtol=2e-5, atol=1e-7)
+    bev = ops.lift_splat_fwd(depth, feat, ws, dims, (X, Y, Z), layout)
+    assert tuple(bev.shape) == (B, Z * C, X, Y)
+    out = bev.float().cpu().numpy()
+    ref = g["out"]
+    tol = 1e-3 if layout != 2 else 8e-3  # bf16 storage: 2^-9 relative
+    assert np.linalg.norm(out - ref) <= tol * np.linalg.norm(ref)
+    assert np.abs(out - ref).max() <= tol * np.abs(ref).max()
+    assert np.array_equal(out == 0, ref == 0)  # same occupancy, empty voxels exactly 0
+    direct = lo.splat_direct_np(g["cell"], g["iz"], depth.cpu().numpy(), feat.cpu().numpy().reshape(B * N, fH * fW, C).transpose(0, 2, 1),
+                                B, N, D, fH, fW, C, X, Y, Z)
+    if layout != 2:
+        np.testing.assert_allclose(out, direct, rtol=2e-5, atol=2e-6 * np.abs(direct).max())
+
+
+@pytest.mark.parametrize("name,bsz", [("g4_full_b1_val", 1), ("g4_full_b4_train", 4)])
+def test_k5_full_size_vs_reference_stats(ops, golden, name, bsz):
+    g = golden(name)
+    B, N, D, fH, fW, C = [int(v) for v in g["dims"]]
+    torch.manual_seed(int(g["seed"]))
+    feat_in = torch.randn(B * N, 512, fH, fW)
+    assert sha(feat_in.numpy()) == str(g["feat_sha256"])
+    fr = lo.create_frustum((128, 352), 16, GRID_DEFAULT["dbound"])
+    dxbxnx = lo.gen_dx_bx(GRID_DEFAULT["xbound"], GRID_DEFAULT["ybound"], GRID_DEFAULT["zbound"])
+    ws, _ = run_k3(ops, g, fr, dxbxnx, want_geom=False)
+    ops.bucket_points(ws)
+    depth, feat = ops.depthnet_softmax(feat_in.cuda(), dev(g["depthnet_weight"]), dev(g["depthnet_bias"]), D, C)
+    outs = {}
+    for layout in LAYOUTS:
+        outs[layout] = ops.lift_splat_fwd(depth, feat, ws, (B, N, D, fH, fW, C), (200, 200, 1), layout).float().cpu().numpy()
+    assert np.array_equal(outs[0], outs[1])  # same sums, two layouts
+    out = outs[0]
+    occ = np.abs(out).sum(1) > 0
+    assert int(occ.sum()) == int(g["n_occupied"])
+    pick = g["pick"]
+    rows = out[pick[:, 0], :, pick[:, 1], pick[:, 2]]
+    ref = g["rows"]
+    assert np.linalg.norm(rows - ref) <= 1e-3 * np.linalg.norm(ref)
+    assert np.abs(rows - ref).max() <= 1e-3 * np.abs(ref).max()
+    assert np.array_equal(np.abs(rows).sum(1) == 0, np.abs(ref).sum(1) == 0)
+    np.testing.assert_allclose(np.sqrt((out.astype(np.float64) ** 2).sum((0, 2, 3))), g["chan_l2"], rtol=1e-3)
+    np.testing.assert_allclose(out.astype(np.float64).sum((0, 2, 3)), g["chan_sum"], rtol=1e-3,
+                               atol=1e-3 * np.abs(g["chan_sum"]).max())
+    assert np.abs(outs[2] - out).max() <= 8e-3 * np.abs(out).max()
+    # run-to-run reproducible (per-voxel sums are ordered by point id)
+    ops.points_to_voxels(fr.cuda(), dev(g["inv_post_rots"]), dev(g["post_trans"]), dev(g["combine"]),
+                         dev(g["trans"]), dxbxnx[0].cuda(), dxbxnx[1].cuda(), (200, 200, 1), ws)
+    ops.bucket_points(ws)
+    again = ops.lift_splat_fwd(depth, feat, ws, (B, N, D, fH, fW, C), (200, 200, 1), 0).cpu().numpy()
+    assert np.array_equal(again, out)
+
+
+@pytest.mark.parametrize("name", ["g4_small_c64", "g4_small_z2"])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_k7_backward_vs_reference(ops, golden, name, channels_last):
+    g, dims, (dx, bx, nx), db = _small(golden, name)
+    B, N, D, fH, fW, C = dims
+    X, Y, Z = [int(v) for v in nx]
+    ws, _ = run_k3(ops, g, torch.from_numpy(g["frustum"]), (dx, bx, nx), want_geom=False)
+    depth, feat = ops.depthnet_softmax(dev(g["feat_in"]), dev(g["depthnet_weight"]), dev(g["depthnet_bias"]), D, C)
+    G = dev(g["grad_out"])
+    if channels_last:
+        G = G.contiguous(memory_format=torch.channels_last)
+    g_logits = ops.lift_splat_bwd(G, ws.voxel, depth, feat, dims, (X, Y, Z)).cpu()
+    # oracle: push the reference's grad_lifted through the outer product + softmax by autograd
+    x_in = torch.from_numpy(g["feat_in"])
+    w, b = torch.from_numpy(g["depthnet_weight"]), torch.from_numpy(g["depthnet_bias"])
+    logits = torch.nn.functional.conv2d(x_in, w, b).requires_grad_(True)
+    dep = logits[:, :D].softmax(1)
+    lifted = dep.unsqueeze(1) * logits[:, D:D + C].unsqueeze(2)
+    lifted.backward(torch.from_numpy(g["grad_lifted"]))
+    ref = logits.grad.numpy()
+    np.testing.assert_allclose(g_logits.numpy(), ref, rtol=2e-4, atol=2e-5 * np.abs(ref).max())
+    # and all the way down to the reference's parameter / input gradients
+    gl = g_logits.reshape(B * N, D + C, fH * fW)
+    gw = torch.einsum("bnp,bkp->nk", gl, x_in.reshape(B * N, 512, fH * fW))
+    np.testing.assert_allclose(gw.numpy(), g["grad_weight"][:, :, 0, 0], rtol=1e-3, atol=1e-4 * np.abs(g["grad_weight"]).max())
+    np.testing.assert_allclose(gl.sum((0, 2)).numpy(), g["grad_bias"], rtol=1e-3, atol=1e-4 * np.abs(g["grad_bias"]).max())
+    gx = torch.einsum("bnp,nk->bkp", gl, w[:, :, 0, 0]).reshape(x_in.shape)
+    np.testing.assert_allclose(gx.numpy(), g["grad_feat_in"], rtol=1e-3, atol=1e-4 * np.abs(g["grad_feat_in"]).max())
+
+
+def test_segmented_sum(ops, golden):
+    g = golden("g5_quickcumsum")
+    ranks = g["ranks"]
+    starts = np.flatnonzero(np.r_[True, ranks[1:] != ranks[:-1], True]).astype(np.int32)
+    x = np.tile(g["x"], (1, 40))[:, :70]
+    y = ops.segmented_sum(dev(x), dev(starts)).cpu().numpy()
+    ref = np.add.reduceat(x.astype(np.float64), starts[:-1], axis=0)
+    np.testing.assert_allclose(y, ref, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(y[:, :2], g["y"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_layout_round_trip(ops, dt):
+    x = torch.randn(3, 70, 9, 13)
+    y = ops.nchw_to_nhwc(x.cuda(), dt)
+    ref = x.permute(0, 2, 3, 1)
+    tol = 0 if dt == 0 else 8e-3
+    assert float((y.float().cpu() - ref).abs().max()) <= tol * 5
+    back = ops.nhwc_to_nchw(y, dt).cpu()
+    assert float((back - x).abs().max()) <= tol * 5
+
+
+CONVS = [
+    # B, H, W, Cx, Cout, k, stride, pad, relu, residual, C2, up
+    (2, 20, 24, 64, 64, 3, 1, 1, True, True, 0, 1),
+    (1, 21, 19, 64, 128, 3, 2, 1, True, False, 0, 1),
+    (2, 20, 20, 64, 64, 7, 2, 3, True, False, 0, 1),
+    (1, 17, 9, 64, 128, 1, 2, 0, False, False, 0, 1),
+    (2, 12, 10, 128, 4, 1, 1, 0, False, False, 0, 1),
+    (1, 5, 7, 256, 256, 3, 1, 1, True, False, 64, 4),
+    (2, 6, 5, 128, 64, 3, 1, 1, True, False, 0, 2),
+    (1, 9, 9, 64, 96, 3, 1, 1, False, False, 64, 1),
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+@pytest.mark.parametrize("dt", [0, 1])
+def test_k8_conv_vs_torch(ops, cfg, dt):
+    B, H, W, Cx, Cout, k, stride, pad, relu, use_res, C2, up = cfg
+    gen = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(B, Cx, H, W, generator=gen)
+    x2 = torch.randn(B, C2, H * up, W * up, generator=gen) if C2 else None
+    w = torch.randn(Cout, Cx + C2, k, k, generator=gen) * ((Cx + C2) * k * k) ** -0.5
+    scale = torch.rand(Cout, generator=gen) + 0.5
+    shift = torch.randn(Cout, generator=gen) * 0.1
+    xin = x
+    if up > 1:
+        xin = bo.upsample_bilinear_ac(x, up)
+    if C2:
+        xin = torch.cat([x2, xin], 1)
+    raw = torch.nn.functional.conv2d(xin, w, None, stride=stride, padding=pad)
+    ref = raw * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    res = torch.randn(ref.shape, generator=gen) if use_res else None
+    if use_res:
+        ref = ref + res
+    if relu:
+        ref = ref.relu()
+    xg = ops.nchw_to_nhwc(x.cuda(), dt)
+    x2g = ops.nchw_to_nhwc(x2.cuda(), dt) if C2 else None
+    resg = ops.nchw_to_nhwc(res.cuda(), dt) if use_res else None
+    wp = ops.pack_conv_weight(w.cuda(), dt)
+    stats = torch.zeros(2 * Cout, device="cuda")
+    y = ops.conv2d_nhwc(xg, wp, (k, k), stride, pad, scale.cuda(), shift.cuda(), resg, relu, x2g, up, stats, dt)
+    out = ops.nhwc_to_nchw(y, dt).cpu()
+    assert out.shape == ref.shape
+    tol = 2e-5 if dt == 0 else 2.5e-2
+    assert float((out - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-6
+    s = stats.cpu()
+    np.testing.assert_allclose(s[:Cout].numpy(), raw.sum((0, 2, 3)).numpy(), rtol=tol * 4, atol=tol * 4 * float(raw.abs().sum((0, 2, 3)).max()))
+    np.testing.assert_allclose(s[Cout:].numpy(), (raw ** 2).sum((0, 2, 3)).numpy(), rtol=max(tol * 4, 1e-4))
+
+
+def test_bad_arguments_raise(ops):
+    ws = ops.SplatWorkspace(10, 10, "cuda")
+    with pytest.raises(ValueError):
+        ops.lift_splat_fwd(torch.zeros(10, device="cuda"), torch.zeros(10, device="cuda"), ws, (1, 1, 1, 1, 10, 7), (10, 1, 1))
+    with pytest.raises(ValueError):
+        ops.depthnet_softmax(torch.zeros(1, 100, 2, 2, device="cuda"), torch.zeros(8, 100, device="cuda"),
+                             torch.zeros(8, device="cuda"), 4, 4)

@@ -174,7 +174,7 @@ def main():
              grad_bias=shell.camencode.depthnet.bias.grad.numpy())
 
     small_case("g4_small_z1", GRID_SMALL, B=2, N=2, fH=3, fW=4, C=4, seed=7)
-    small_case("g4_small_z2", GRID_SMALL_Z2, B=2, N=3, fH=2, fW=5, C=8, seed=8)
+    small_case("g4_small_z2", GRID_SMALL_Z2, B=2, N=3, fH=2, fW=5, C=64, seed=8)
     small_case("g4_small_c64", GRID_SMALL, B=1, N=2, fH=2, fW=3, C=64, seed=9)
 
     # ---- G4b full-size splat stats -------------------------------------------
