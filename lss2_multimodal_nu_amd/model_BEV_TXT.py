@@ -1,0 +1,293 @@
+"""Drop-in `LSS` / `BEV_TXT` for the reference's `src/model_BEV_TXT.py`
+(`LSS` :11-140, `BEV_TXT` :143-334, factories :337-340).
+
+Same constructor arguments, same `forward(x, rots, trans, intrins, post_rots,
+post_trans)` signature, same public methods (`create_frustum`, `get_geometry`,
+`get_cam_feats`, `voxel_pooling`, `get_voxels`), same `state_dict` entries
+(`dx bx nx frustum camencode.* bevencode.*` ...).  Underneath, the camera->BEV
+path is five HIP launches (csrc/):
+
+    K2 depthnet+softmax  ||  K3 points->voxels(+histogram) -> K4 alloc, fill
+                         \\________________________________________________/
+                                               K5 fused lift-splat
+
+and the lifted (B,N,D,fH,fW,C) tensor, the sort, the cumsum and the zero-filled
+scatter target of the reference never exist.
+
+What is NOT here: the EfficientNet-B4 trunk (`Encoder`, third-party weights, a
+network fetch).  `encoder=` accepts any module producing the (B*N, 512, fH, fW)
+trunk features; the default passes such features straight through.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .heads import (BevPost, Embedder_f1, Embedder_f2, Embedder_lr1, Embedder_lr2, Predictor,
+                    SceneUnder)
+from .modules import BevEncode, CamEncode, _PRECISIONS, _needs_autograd, default_precision
+from .tools import QuickCumsum, cumsum_trick, gen_dx_bx  # noqa: F401  (reference's import surface)
+
+
+class TrunkFeatures(nn.Module):
+    """Stand-in for the reference's `Encoder` slot: accepts trunk features
+    (B*N, 512, fH, fW) or (B, N, 512, fH, fW) and returns them as (B*N, 512, fH, fW)."""
+
+    def forward(self, x):
+        if x.dim() == 5:
+            if x.shape[2] == 3:
+                raise RuntimeError(
+                    "got raw camera images (B,N,3,H,W): the EfficientNet trunk of the reference's "
+                    "Encoder is not bundled (third-party weights); pass encoder=<your trunk module> "
+                    "to the model or feed (B*N,512,H/16,W/16) trunk features")
+            x = x.reshape(-1, *x.shape[2:])
+        return x
+
+
+class _LiftSplatFn(torch.autograd.Function):
+    """depthnet -> softmax -> lift -> splat as ONE differentiable op (K2,K5 | K7).
+    Index tensors come from the workspace (K3/K4 already ran)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, ws, dims, nx, math, layout):
+        B, N, D, fH, fW, C = dims
+        depth, feat = ops.depthnet_softmax(x.contiguous(), weight, bias, D, C, math)
+        bev = ops.lift_splat_fwd(depth, feat, ws, dims, nx, layout)
+        ctx.save_for_backward(x, weight, depth, feat, ws.voxel.clone())
+        ctx.dims, ctx.nx = dims, nx
+        return bev
+
+    @staticmethod
+    def backward(ctx, grad_bev):
+        x, weight, depth, feat, voxel = ctx.saved_tensors
+        B, N, D, fH, fW, C = ctx.dims
+        g_logits = ops.lift_splat_bwd(grad_bev.float(), voxel, depth, feat, ctx.dims, ctx.nx)
+        gl = g_logits.view(B * N, D + C, fH * fW)
+        xf = x.reshape(B * N, -1, fH * fW)
+        w2 = weight.reshape(D + C, -1)
+        # the two plain GEMMs of the 1x1-conv backward go to the BLAS library
+        gx = torch.matmul(w2.t().unsqueeze(0), gl).view_as(x) if ctx.needs_input_grad[0] else None
+        gw = torch.einsum("bnp,bkp->nk", gl, xf).view_as(weight) if ctx.needs_input_grad[1] else None
+        gb = gl.sum((0, 2)) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None, None, None, None, None
+
+
+class _VoxelPoolFn(torch.autograd.Function):
+    """API-compat `voxel_pooling(geom, x)` on an already-lifted x: sums by voxel
+    (K5 with unit depth weights), backward = gather of the voxel's gradient row."""
+
+    @staticmethod
+    def forward(ctx, xflat, ws, B, nx, C):
+        P = xflat.shape[0]
+        ones = torch.ones(P, dtype=torch.float32, device=xflat.device)
+        bev = ops.lift_splat_fwd(ones, xflat, ws, (B, P // B, 1, 1, 1, C), nx, ops.BEV_NCHW_F32)
+        ctx.save_for_backward(ws.voxel.clone())
+        ctx.shape = (B, nx, C)
+        return bev
+
+    @staticmethod
+    def backward(ctx, g):
+        voxel, = ctx.saved_tensors
+        B, (X, Y, Z), C = ctx.shape
+        rows = g.view(B, Z, C, X, Y).permute(0, 3, 4, 1, 2).reshape(B * X * Y * Z, C)
+        gx = rows[voxel.clamp(min=0).long()] * (voxel >= 0).unsqueeze(1)
+        return gx, None, None, None, None
+
+
+class _LiftSplatMixin:
+    """Everything `LSS` and `BEV_TXT` share on the camera->BEV path."""
+
+    def _init_lift_splat(self, bsize, grid_conf, data_aug_conf, outC, encoder, precision):
+        self.grid_conf = grid_conf
+        self.data_aug_conf = data_aug_conf
+        self.bsize = bsize
+        dx, bx, nx = gen_dx_bx(grid_conf["xbound"], grid_conf["ybound"], grid_conf["zbound"])
+        self.dx = nn.Parameter(dx, requires_grad=False)
+        self.bx = nn.Parameter(bx, requires_grad=False)
+        self.nx = nn.Parameter(nx, requires_grad=False)
+        self.downsample = 16
+        self.camC = 64
+        self.frustum = self.create_frustum()
+        self.D = self.frustum.shape[0]
+        self.encoder = encoder if encoder is not None else TrunkFeatures()
+        self.camencode = CamEncode(self.D, self.camC, self.downsample)
+        self.bevencode = BevEncode(inC=self.camC, outC=outC, precision=precision)
+        self.precision = precision
+        self.use_quickcumsum = True  # kept for API compatibility; both settings take the HIP path
+        self._nx_cache = None
+        self._ws = {}
+
+    # -- grid bookkeeping ---------------------------------------------------
+    def create_frustum(self):
+        """(D, fH, fW, 3) image-plane sample grid (x_pix, y_pix, depth)."""
+        ogfH, ogfW = self.data_aug_conf["final_dim"]
+        fH, fW = ogfH // self.downsample, ogfW // self.downsample
+        ds = torch.arange(*self.grid_conf["dbound"], dtype=torch.float)
+        xs = torch.linspace(0, ogfW - 1, fW, dtype=torch.float)
+        ys = torch.linspace(0, ogfH - 1, fH, dtype=torch.float)
+        frustum = torch.stack(torch.broadcast_tensors(xs.view(1, 1, fW), ys.view(1, fH, 1), ds.view(-1, 1, 1)), -1)
+        return nn.Parameter(frustum.contiguous(), requires_grad=False)
+
+    def _nx_ints(self):
+        """(X, Y, Z) as python ints; one D2H read per change of the nx Parameter."""
+        key = (self.nx.data_ptr(), self.nx._version)
+        if self._nx_cache is None or self._nx_cache[0] != key:
+            self._nx_cache = (key, tuple(int(v) for v in self.nx.detach().cpu()))
+        return self._nx_cache[1]
+
+    def _workspace(self, P, nvox, device):
+        key = (P, nvox, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = self._ws[key] = ops.SplatWorkspace(P, nvox, device)
+        return ws
+
+    # -- calibration ----------------------------------------------------------
+    def _calib_matrices(self, rots, intrins, post_rots):
+        """inv(post_rots) and rots @ inv(intrins), computed with torch ON THE HOST:
+        the voxel index of a point must equal the reference CPU path's bit for
+        bit, and only the host LAPACK reproduces its 3x3 inverses.
+        CPU calibration tensors (what a DataLoader hands over) cost no sync."""
+        r, i, p = (t.detach().float().cpu() for t in (rots, intrins, post_rots))
+        return torch.inverse(p), r.matmul(torch.inverse(i))
+
+    def _upload(self, device, *ts):
+        # one pinned staging block per call: torch's caching host allocator keeps it
+        # alive until the async copy has run, so back-to-back steps never race on it
+        flat = torch.cat([t.detach().float().reshape(-1).cpu() for t in ts]).pin_memory()
+        d = flat.to(device, non_blocking=True)
+        out, o = [], 0
+        for t in ts:
+            out.append(d[o:o + t.numel()].view(t.shape))
+            o += t.numel()
+        return out
+
+    def _index_points(self, rots, trans, intrins, post_rots, post_trans, want_geom=False):
+        """K3 (+K4): fills the workspace; returns (workspace, geom or None)."""
+        dev = self.frustum.device
+        B, Ncam = trans.shape[:2]
+        D, fH, fW, _ = self.frustum.shape
+        nx = self._nx_ints()
+        inv_pr, comb = self._calib_matrices(rots, intrins, post_rots)
+        inv_pr, comb, ptr, trn = self._upload(dev, inv_pr, comb, post_trans, trans)
+        ws = self._workspace(B * Ncam * D * fH * fW, B * nx[0] * nx[1] * nx[2], dev)
+        geom = ops.points_to_voxels(self.frustum.detach(), inv_pr, ptr, comb, trn, self.dx.detach(),
+                                    self.bx.detach(), nx, ws, want_geom=want_geom)
+        return ws, geom
+
+    # -- reference API ----------------------------------------------------------
+    def get_geometry(self, rots, trans, intrins, post_rots, post_trans):
+        """(x,y,z) ego-frame location of every frustum point: B x N x D x fH x fW x 3."""
+        ws, geom = self._index_points(rots, trans, intrins, post_rots, post_trans, want_geom=True)
+        ops.bucket_points(ws)  # leave the histogram counters at zero (K4 contract)
+        return geom
+
+    def get_cam_feats(self, x):
+        """B x N x D x fH x fW x C lifted features (materialised: API compatibility only)."""
+        BN, C, imH, imW = x.shape
+        B = self.bsize
+        N = BN // B
+        x = self.camencode(x)
+        x = x.view(B, N, self.camC, self.D, imH, imW)
+        return x.permute(0, 1, 3, 4, 5, 2)
+
+    def voxel_pooling(self, geom_feats, x):
+        """Sum lifted features into the BEV grid: (B,N,D,H,W,3), (B,N,D,H,W,C) -> (B, C*nz, nx, ny)."""
+        B, N, D, H, W, C = x.shape
+        nx = self._nx_ints()
+        P = B * N * D * H * W
+        dev = x.device
+        ws = self._workspace(P, B * nx[0] * nx[1] * nx[2], dev)
+        ops.geom_to_voxels(geom_feats.detach().float().contiguous(), self.dx.detach(), self.bx.detach(), nx, B, ws)
+        ops.bucket_points(ws)
+        return _VoxelPoolFn.apply(x.reshape(P, C).float().contiguous(), ws, B, nx, C)
+
+    def _lift_splat(self, x, rots, trans, intrins, post_rots, post_trans, layout):
+        """Fused path: trunk features + calibration -> BEV (logical (B, C*nz, nx, ny))."""
+        BN, _, fH, fW = x.shape
+        B = self.bsize
+        if BN % B != 0 or tuple(trans.shape[:2]) != (B, BN // B):
+            raise RuntimeError("features for %d images do not match bsize=%d x %s cameras"
+                               % (BN, B, tuple(trans.shape[:2])))
+        if (self.D, fH, fW) != tuple(self.frustum.shape[:3]):
+            raise RuntimeError("feature map %dx%d does not match the frustum %s"
+                               % (fH, fW, tuple(self.frustum.shape[:3])))
+        ws, _ = self._index_points(rots, trans, intrins, post_rots, post_trans)
+        ops.bucket_points(ws)
+        dims = (B, BN // B, self.D, fH, fW, self.camC)
+        ce = self.camencode
+        if _needs_autograd(ce, x):
+            return _LiftSplatFn.apply(x.float(), ce.depthnet.weight, ce.depthnet.bias, ws, dims,
+                                      self._nx_ints(), _PRECISIONS[ce.math], layout)
+        depth, feat = ce.depth_and_context(x)
+        return ops.lift_splat_fwd(depth, feat, ws, dims, self._nx_ints(), layout)
+
+    def get_voxels(self, x, rots, trans, intrins, post_rots, post_trans):
+        return self._lift_splat(x, rots, trans, intrins, post_rots, post_trans, ops.BEV_NCHW_F32)
+
+    def _bev(self, x, rots, trans, intrins, post_rots, post_trans):
+        """get_voxels + bevencode with the BEV grid handed over channels-last (bf16
+        when the conv path computes in bf16) - no NCHW fp32 round trip."""
+        be = self.bevencode
+        if _needs_autograd(be, x) or _needs_autograd(self.camencode, x):
+            return be(self.get_voxels(x, rots, trans, intrins, post_rots, post_trans))
+        dt = _PRECISIONS[be.precision or default_precision()]
+        layout = ops.BEV_NHWC_BF16 if dt == ops.DT_BF16 else ops.BEV_NHWC_F32
+        grid = self._lift_splat(x, rots, trans, intrins, post_rots, post_trans, layout)
+        y = be.forward_nhwc(grid.permute(0, 2, 3, 1), dt)
+        return ops.nhwc_to_nchw(y, dt)
+
+
+class LSS(_LiftSplatMixin, nn.Module):
+    def __init__(self, bsize, grid_conf, data_aug_conf, outC, encoder=None, precision=None):
+        nn.Module.__init__(self)
+        self._init_lift_splat(bsize, grid_conf, data_aug_conf, outC, encoder, precision)
+
+    def forward(self, x, rots, trans, intrins, post_rots, post_trans):
+        x = self.encoder(x)
+        return self._bev(x, rots, trans, intrins, post_rots, post_trans)
+
+
+class BEV_TXT(_LiftSplatMixin, nn.Module):
+    """BEV segmentation + driving action / description heads.  The BEV half is the
+    HIP path above; the TXT half (ASPP scene features, per-camera embedders, linear
+    predictors) is stock PyTorch, as SURVEY.md section 2 scopes it."""
+
+    def __init__(self, bsize, grid_conf, data_aug_conf, outC, encoder=None, precision=None):
+        nn.Module.__init__(self)
+        self._init_lift_splat(bsize, grid_conf, data_aug_conf, outC, encoder, precision)
+        self.sceneunder = SceneUnder()
+        self.embeder_f1 = Embedder_f1(in_channels=256, out_channels=32)
+        self.embeder_f2 = Embedder_f2(out_channels=40)
+        self.embeder_lr1 = Embedder_lr1(in_channels=256, out_channels=32)
+        self.embeder_lr2 = Embedder_lr2(out_channels=40)
+        self.predictorf1 = Predictor(num_in=40, classes=4)
+        self.predictorf2 = Predictor(num_in=40, classes=4)
+        self.predictorlr = Predictor(num_in=40, classes=1)
+        self.bevpost = BevPost()
+
+    def forward(self, x, rots, trans, intrins, post_rots, post_trans):
+        x = self.encoder(x)
+        bev = self._bev(x, rots, trans, intrins, post_rots, post_trans)
+
+        # TXT half: the BEV crop around the ego vehicle joins every camera's features
+        bev_post = self.bevpost(bev.detach()[:, :, 60:140, 56:144])
+        scene = self.sceneunder(x)
+        ncams = self.data_aug_conf["Ncams"]
+        cam = lambda i: scene[i::ncams]  # noqa: E731
+
+        def side(i):
+            y = torch.cat([self.embeder_lr1(cam(i)), bev_post], dim=1)
+            return self.predictorlr(self.embeder_lr2(y))
+
+        y_f = self.embeder_f2(torch.cat([self.embeder_f1(cam(1)), bev_post], dim=1))
+        desc_f, act_f = self.predictorf1(y_f), self.predictorf2(y_f)
+        desc = torch.cat([desc_f, side(0), side(3), side(2), side(5)], dim=1)
+        return bev, act_f, desc
+
+
+def compile_model_lss(bsize, grid_conf, data_aug_conf, outC, **kw):
+    return LSS(bsize, grid_conf, data_aug_conf, outC, **kw)
+
+
+def compile_model_bevtxt(bsize, grid_conf, data_aug_conf, outC, **kw):
+    return BEV_TXT(bsize, grid_conf, data_aug_conf, outC, **kw)

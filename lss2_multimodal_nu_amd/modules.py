@@ -1,0 +1,257 @@
+"""Host-side mirror of the hot-path building blocks of the reference's
+`src/modules.py`: `Up` (:9-27), `CamEncode` (:69-91), `BevEncode` (:94-130).
+
+Constructor signatures, `forward()` signatures, parameter names / shapes and the
+default initialisation follow the reference (and torchvision 0.13.1's resnet18
+for `layer1..3`), so a reference `state_dict` loads with `strict=True` into the
+corresponding module here.  torch.nn modules are used as PARAMETER CONTAINERS;
+the inference arithmetic runs in the HIP kernels of csrc/ (conv_mfma.hip,
+depthnet.hip) through the C ABI - there is no eager fallback for it.
+
+Training mode (batch-statistics BatchNorm + autograd through the convs) is not
+native yet: it runs the same parameters through torch's GPU ops (MIOpen).  See
+DESIGN.md "Out of scope / not yet native".
+"""
+import os
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import ops
+
+_PRECISIONS = {"bf16": ops.DT_BF16, "fp32": ops.DT_F32}
+
+
+def default_precision():
+    """Conv-path math: 'bf16' (bf16 MFMA, fp32 accumulate - BASELINE config 2) or
+    'fp32' (f32 MFMA, exact fp32 FMA chains - the parity mode)."""
+    p = os.environ.get("LSS_PRECISION", "bf16")
+    if p not in _PRECISIONS:
+        raise ValueError("LSS_PRECISION must be one of %s" % sorted(_PRECISIONS))
+    return p
+
+
+def _needs_autograd(module, *inputs):
+    if not torch.is_grad_enabled():
+        return False
+    return module.training or any(t is not None and t.requires_grad for t in inputs) \
+        or any(p.requires_grad for p in module.parameters())
+
+
+class _FoldedConv:
+    """Packed weights + eval-mode BatchNorm folded into (scale, shift) for one
+    conv of the HIP path; rebuilt only when a source tensor changes."""
+
+    def __init__(self, conv, bn=None):
+        self.conv, self.bn = conv, bn
+        self.key = None
+        self.w = self.scale = self.shift = None
+
+    def _sources(self):
+        src = [self.conv.weight]
+        if self.conv.bias is not None:
+            src.append(self.conv.bias)
+        if self.bn is not None:
+            src += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+        return src
+
+    def get(self, dt):
+        src = self._sources()
+        key = (dt,) + tuple((t.data_ptr(), t._version) for t in src)
+        if key != self.key:
+            with torch.no_grad():
+                self.w = ops.pack_conv_weight(self.conv.weight.detach().float().contiguous(), dt)
+                if self.bn is not None:
+                    inv = torch.rsqrt(self.bn.running_var.float() + self.bn.eps)
+                    self.scale = (self.bn.weight.float() * inv).contiguous()
+                    self.shift = (self.bn.bias.float() - self.bn.running_mean.float() * self.scale).contiguous()
+                else:
+                    self.scale = None
+                    self.shift = self.conv.bias.detach().float().contiguous() if self.conv.bias is not None else None
+            self.key = key
+        return self.w, self.scale, self.shift
+
+    def run(self, x, dt, relu, residual=None, x2=None, up=1):
+        w, scale, shift = self.get(dt)
+        c = self.conv
+        return ops.conv2d_nhwc(x, w, c.kernel_size, c.stride[0], c.padding[0], scale, shift, residual, relu,
+                               x2=x2, up=up, dt=dt)
+
+
+def _to_nhwc(x, dt):
+    """(B,C,H,W) fp32 (contiguous or channels_last) -> (B,H,W,C) activations in dt."""
+    if x.dtype == torch.bfloat16 and dt == ops.DT_BF16 and x.is_contiguous(memory_format=torch.channels_last):
+        return x.permute(0, 2, 3, 1)  # already NHWC bf16 (the fused splat hand-off)
+    x = x.float()
+    if dt == ops.DT_F32 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+        return x.permute(0, 2, 3, 1)
+    return ops.nchw_to_nhwc(x.contiguous(), dt)
+
+
+class Up(nn.Module):
+    """Bilinear (align_corners=True) upsample of x1, concat [x2, x1], two 3x3
+    conv-BN-ReLU.  On the HIP path the upsample and the concat are fused into the
+    first conv's operand gather: neither tensor is materialised."""
+
+    def __init__(self, in_channels, out_channels, scale_factor=2, precision=None):
+        super().__init__()
+        self.up = nn.Upsample(scale_factor=scale_factor, mode="bilinear", align_corners=True)
+        self.conv = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True))
+        self.scale_factor = int(scale_factor)
+        self.precision = precision
+        self._f0 = _FoldedConv(self.conv[0], self.conv[1])
+        self._f1 = _FoldedConv(self.conv[3], self.conv[4])
+
+    def _nhwc(self, x1, x2, dt):
+        y = self._f0.run(x1, dt, relu=True, x2=x2, up=self.scale_factor)
+        return self._f1.run(y, dt, relu=True)
+
+    def forward(self, x1, x2):
+        if _needs_autograd(self, x1, x2):
+            x1 = self.up(x1)
+            return self.conv(torch.cat([x2, x1], dim=1))
+        dt = _PRECISIONS[self.precision or default_precision()]
+        y = self._nhwc(_to_nhwc(x1, dt), _to_nhwc(x2, dt), dt)
+        return ops.nhwc_to_nchw(y, dt)
+
+
+class CamEncode(nn.Module):
+    """depthnet 1x1 conv -> softmax over D depth bins -> depth (x) context outer
+    product.  `forward` / `get_depth_feat` materialise the (B*N, C, D, fH, fW)
+    lifted tensor only because that is their return value; the fused LSS path
+    calls `depth_and_context` and never forms it."""
+
+    def __init__(self, D, C, downsample, math="fp32"):
+        super().__init__()
+        self.D = D
+        self.C = C
+        self.depthnet = nn.Conv2d(512, self.D + self.C, kernel_size=1, padding=0)
+        self.math = math
+
+    def get_depth_dist(self, x, eps=1e-20):
+        return x.softmax(dim=1)
+
+    def depth_and_context(self, x):
+        """HIP K2: x (BN,Cin,fH,fW) -> depth (BN,D,fH,fW), context (BN,fH,fW,C)."""
+        return ops.depthnet_softmax(x.float().contiguous(), self.depthnet.weight.detach(),
+                                    self.depthnet.bias.detach(), self.D, self.C, _PRECISIONS[self.math])
+
+    def get_depth_feat(self, x):
+        if _needs_autograd(self, x):
+            y = self.depthnet(x)
+            depth = self.get_depth_dist(y[:, :self.D])
+            return depth, depth.unsqueeze(1) * y[:, self.D:(self.D + self.C)].unsqueeze(2)
+        depth, ctx = self.depth_and_context(x)
+        return depth, depth.unsqueeze(1) * ctx.permute(0, 3, 1, 2).unsqueeze(2)
+
+    def forward(self, x):
+        depth, x = self.get_depth_feat(x)
+        return x
+
+
+class BasicBlock(nn.Module):
+    """torchvision resnet BasicBlock (expansion 1): conv3x3-BN-ReLU-conv3x3-BN,
+    + identity or [conv1x1(stride)-BN], ReLU."""
+
+    def __init__(self, inplanes, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1 or inplanes != planes:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False),
+                                            nn.BatchNorm2d(planes))
+        self._f1 = _FoldedConv(self.conv1, self.bn1)
+        self._f2 = _FoldedConv(self.conv2, self.bn2)
+        self._fd = _FoldedConv(self.downsample[0], self.downsample[1]) if self.downsample is not None else None
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + idt)
+
+    def _nhwc(self, x, dt):
+        idt = x if self._fd is None else self._fd.run(x, dt, relu=False)
+        t = self._f1.run(x, dt, relu=True)
+        return self._f2.run(t, dt, relu=True, residual=idt)
+
+
+def _resnet18_layer(inplanes, planes, stride):
+    return nn.Sequential(BasicBlock(inplanes, planes, stride), BasicBlock(planes, planes, 1))
+
+
+class BevEncode(nn.Module):
+    """BEV decoder: 7x7/2 stem, resnet18 layer1-3, Up(x4) with the layer1 skip,
+    x2 upsample + 3x3 conv + 1x1 head.  (B, inC, X, Y) -> (B, outC, X, Y)."""
+
+    def __init__(self, inC, outC, precision=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inC, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.layer1 = _resnet18_layer(64, 64, 1)
+        self.layer2 = _resnet18_layer(64, 128, 2)
+        self.layer3 = _resnet18_layer(128, 256, 2)
+        # resnet18(pretrained=False, zero_init_residual=True) initialisation
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        for m in self.modules():
+            if isinstance(m, BasicBlock):
+                nn.init.constant_(m.bn2.weight, 0)
+        # conv1 is a plain nn.Conv2d in the reference (default init), as are up1 / up2
+        self.conv1.reset_parameters()
+        self.up1 = Up(64 + 256, 256, scale_factor=4, precision=precision)
+        self.up2 = nn.Sequential(
+            nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True),
+            nn.Conv2d(256, 128, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(128),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(128, outC, kernel_size=1, padding=0),
+        )
+        self.precision = precision
+        self._stem = _FoldedConv(self.conv1, self.bn1)
+        self._up2a = _FoldedConv(self.up2[1], self.up2[2])
+        self._up2b = _FoldedConv(self.up2[4], None)
+
+    def _forward_autograd(self, x):
+        x = self.relu(self.bn1(self.conv1(x)))
+        x1 = self.layer1(x)
+        x = self.layer3(self.layer2(x1))
+        x = self.up1(x, x1)
+        return self.up2(x)
+
+    def forward_nhwc(self, x, dt):
+        """HIP path on channels-last activations: x (B,X,Y,inC) in dt -> (B,X,Y,outC) in dt."""
+        x = self._stem.run(x, dt, relu=True)
+        for blk in self.layer1:
+            x = blk._nhwc(x, dt)
+        x1 = x
+        for blk in self.layer2:
+            x = blk._nhwc(x, dt)
+        for blk in self.layer3:
+            x = blk._nhwc(x, dt)
+        x = self.up1._nhwc(x, x1, dt)
+        x = self._up2a.run(x, dt, relu=True, up=2)
+        return self._up2b.run(x, dt, relu=False)
+
+    def forward(self, x):
+        if _needs_autograd(self, x):
+            return self._forward_autograd(x.float() if x.dtype != torch.float32 else x)
+        dt = _PRECISIONS[self.precision or default_precision()]
+        y = self.forward_nhwc(_to_nhwc(x, dt), dt)
+        return ops.nhwc_to_nchw(y, dt)
