@@ -16,6 +16,8 @@
 // contiguous run of channels (32 bf16 / 4 f32) and k-step s consumes its s-th
 // piece on BOTH operands, so activations (NHWC) and weights ([tap][co][ci]) keep
 // their natural layouts - only the order of the K summation is permuted.
+#include <stdlib.h>
+
 #include "lss_common.h"
 
 namespace {
@@ -217,6 +219,148 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// conv3x3_lds_kernel: 3x3 / stride 1 / pad 1, bf16 - the shape that carries 95 %
+// of BevEncode's FLOPs.  Output-stationary, LDS-tiled:
+//   * workgroup (256 threads, 2 per CU) = TH x 16 output pixels x BN output
+//     channels of one image; every wave owns 4 pixel rows x 64 channels =
+//     2 x 2 tiles of v_mfma_f32_32x32x16_bf16 (64 accumulator registers);
+//   * per 64-channel chunk of the input the (TH+2) x 18 halo'd input patch is
+//     gathered ONCE into LDS (the fused bilinear-upsample / concat gather runs
+//     here, once per element instead of once per tap) and re-used by all 9
+//     taps through shifted ds_read_b128 windows;
+//   * per (chunk, tap) step the BN x 64 weight slab is staged global -> registers
+//     -> LDS, double-buffered, the loads of step s+1 in flight behind the 16
+//     MFMAs of step s; one barrier per step.
+// LDS rows (one pixel position / one output channel = 64 bf16) are padded from
+// 128 to 144 B so the 16-lane groups of ds_read_b128 spread over all 64 banks.
+template <int TH, int BN, bool FUSED>
+__global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(ConvArgs a, int tilesX, int tilesY) {
+  constexpr int TW = 16, IW = TW + 2, IH = TH + 2, ROWB = 144;
+  constexpr int IN_BYTES = IH * IW * ROWB;
+  constexpr int W_BYTES = BN * ROWB;
+  constexpr int WPT = BN / 32;     // 16-B weight pieces per thread per step
+  constexpr int WCOLS = BN / 64;   // waves along the channel axis
+  __shared__ __attribute__((aligned(16))) unsigned char smem[IN_BYTES + 2 * W_BYTES];
+  unsigned char* in_tile = smem;
+  unsigned char* w_tile = smem + IN_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  int t = blockIdx.x;
+  const int tx = t % tilesX; t /= tilesX;
+  const int ty = t % tilesY;
+  const int b = t / tilesY;
+  const int oy0 = ty * TH, ox0 = tx * TW, n0 = blockIdx.y * BN;
+  const int wc = wave % WCOLS, wr = wave / WCOLS;
+  const int prow0 = wr * 4;
+
+  int aoff[2], boff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    aoff[i] = ((prow0 + 2 * i + (r >> 4)) * IW + (r & 15)) * ROWB + h * 64;
+    boff[i] = (wc * 64 + i * 32 + r) * ROWB + h * 64;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const unsigned short* wg = reinterpret_cast<const unsigned short*>(a.w);
+  const int nsteps = (a.Cin / 64) * 9;
+  uint4 wreg[WPT];
+  auto load_w = [&](int step) {
+    const int tap = step % 9, chunk = step / 9;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int p = tid + i * 256;
+      const int row = p >> 3, part = p & 7;
+      const int co = n0 + row;
+      wreg[i] = make_uint4(0, 0, 0, 0);
+      if (co < a.Cout)
+        wreg[i] = *reinterpret_cast<const uint4*>(wg + ((size_t)tap * a.Cout + co) * a.Cin + chunk * 64 + part * 8);
+    }
+  };
+  load_w(0);
+
+  for (int step = 0; step < nsteps; ++step) {
+    const int tap = step % 9, chunk = step / 9;
+    if (tap == 0) {
+      if (step > 0) __syncthreads();  // every wave is done with the previous chunk's patch
+      for (int q = tid; q < IH * IW * 8; q += 256) {
+        const int pos = q >> 3, part = q & 7;
+        const int py = pos / IW, px = pos - py * IW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
+          v = load_in_piece<unsigned short, FUSED>(a, b, iy, ix, chunk * 64 + part * 8);
+        *reinterpret_cast<uint4*>(in_tile + pos * ROWB + part * 16) = v;
+      }
+    }
+    unsigned char* wbuf = w_tile + (step & 1) * W_BYTES;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int p = tid + i * 256;
+      *reinterpret_cast<uint4*>(wbuf + (p >> 3) * ROWB + (p & 7) * 16) = wreg[i];
+    }
+    __syncthreads();
+    if (step + 1 < nsteps) load_w(step + 1);
+    const int toff = ((tap / 3) * IW + (tap % 3)) * ROWB;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(in_tile + aoff[0] + toff + s * 16);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(in_tile + aoff[1] + toff + s * 16);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wbuf + boff[0] + s * 16);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wbuf + boff[1] + s * 16);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+
+  // epilogue: D[row = (i&3) + 8*(i>>2) + 4*h][col = r]; row -> pixel (row>>4, row&15) of the row tile
+  unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
+  const unsigned short* res = reinterpret_cast<const unsigned short*>(a.residual);
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int co = n0 + wc * 64 + ct * 32 + r;
+    const bool cok = co < a.Cout;
+    const float sc = (cok && a.scale) ? a.scale[co] : 1.f;
+    const float sh = (cok && a.shift) ? a.shift[co] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int oy = oy0 + prow0 + 2 * rt + (row >> 4), ox = ox0 + (row & 15);
+        if (cok && oy < a.Ho && ox < a.Wo) {
+          const float raw = acc[rt][ct][i];
+          s1 += raw;
+          s2 += raw * raw;
+          float v = raw * sc + sh;
+          const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
+          if (res) v += lss_bf2f(res[o]);
+          if (a.relu) v = fmaxf(v, 0.f);
+          y[o] = lss_f2bf(v);
+        }
+      }
+    }
+    if (a.stats) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0 && cok) {
+        atomicAdd(a.stats + co, s1);
+        atomicAdd(a.stats + a.Cout + co, s2);
+      }
+    }
+  }
+}
+
 // OIHW fp32 -> [tap][co][ci] in T
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, int Cout, int Cin, int KHW,
@@ -291,6 +435,22 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   dim3 grid(lss_cdiv(M, 128), lss_cdiv(Cout, 64));
   if (grid.y > 65535) return LSS_E_SHAPE;
   hipStream_t st = lss_stream(stream);
+  if (dt == LSS_DT_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && a.Cin % 64 == 0 &&
+      getenv("LSS_CONV_DIRECT") == nullptr) {
+    const int tilesX = lss_cdiv(a.Wo, 16);
+    if (Cout <= 64) {
+      const int tilesY = lss_cdiv(a.Ho, 16);
+      dim3 g(tilesX * tilesY * B, lss_cdiv(Cout, 64));
+      if (fused) hipLaunchKernelGGL((conv3x3_lds_kernel<16, 64, true>), g, dim3(256), 0, st, a, tilesX, tilesY);
+      else hipLaunchKernelGGL((conv3x3_lds_kernel<16, 64, false>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    } else {
+      const int tilesY = lss_cdiv(a.Ho, 8);
+      dim3 g(tilesX * tilesY * B, lss_cdiv(Cout, 128));
+      if (fused) hipLaunchKernelGGL((conv3x3_lds_kernel<8, 128, true>), g, dim3(256), 0, st, a, tilesX, tilesY);
+      else hipLaunchKernelGGL((conv3x3_lds_kernel<8, 128, false>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    }
+    return lss_launch_status();
+  }
   if (dt == LSS_DT_BF16) {
     if (fused) hipLaunchKernelGGL((conv_direct_kernel<unsigned short, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_direct_kernel<unsigned short, false>), grid, dim3(256), 0, st, a);

@@ -19,6 +19,46 @@ def _f32c(t, name, shape=None):
     return t
 
 
+class KernelTimer:
+    """Optional HIP-event brackets around native launches (bench.py uses it for
+    the roofline numbers).  Events are recorded on torch's current stream - the
+    stream the kernels are enqueued on."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def bracket(self, tag):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.spans.setdefault(tag, []).append((s, e))
+        return s, e
+
+    def totals_ms(self):
+        """tag -> (launches, total ms); call after a device synchronize."""
+        return {t: (len(v), sum(s.elapsed_time(e) for s, e in v)) for t, v in self.spans.items()}
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
+class _timed:
+    def __init__(self, tag):
+        self.ev = _timer.bracket(tag) if (_timer is not None and tag) else None
+
+    def __enter__(self):
+        if self.ev:
+            self.ev[0].record()
+
+    def __exit__(self, *a):
+        if self.ev:
+            self.ev[1].record()
+        return False
+
+
 class SplatWorkspace:
     """Index buffers of one (B,N,D,fH,fW | X,Y,Z) problem, reused across steps.
 
@@ -96,7 +136,7 @@ def depthnet_softmax(x, weight, bias, D, C, math=DT_F32):
     return depth, feat
 
 
-def lift_splat_fwd(depth, feat, ws, dims, nx, layout=BEV_NCHW_F32):
+def lift_splat_fwd(depth, feat, ws, dims, nx, layout=BEV_NCHW_F32, tag="lift_splat_fwd"):
     """K5/K6.  dims = (B,N,D,fH,fW,C).  Returns the BEV tensor with LOGICAL shape
     (B, Z*C, X, Y): contiguous for NCHW_F32, channels_last strides for NHWC_*."""
     B, Ncam, D, fH, fW, C = dims
@@ -115,9 +155,10 @@ def lift_splat_fwd(depth, feat, ws, dims, nx, layout=BEV_NCHW_F32):
         dt = torch.float32 if layout == BEV_NHWC_F32 else torch.bfloat16
         bev = torch.empty(B, X, Y, Z * C, dtype=dt, device=dev)
         out = bev.permute(0, 3, 1, 2)
-    N.check(N.lib().lss_lift_splat_fwd(N.ptr(depth), N.ptr(feat), N.ptr(ws.vox_list), N.ptr(ws.point_id),
-                                       B, Ncam, D, fH, fW, C, X, Y, Z, N.ptr(bev), layout, N.stream()),
-            "lss_lift_splat_fwd")
+    with _timed(tag):
+        N.check(N.lib().lss_lift_splat_fwd(N.ptr(depth), N.ptr(feat), N.ptr(ws.vox_list), N.ptr(ws.point_id),
+                                           B, Ncam, D, fH, fW, C, X, Y, Z, N.ptr(bev), layout, N.stream()),
+                "lss_lift_splat_fwd")
     return out
 
 
@@ -169,7 +210,7 @@ def pack_conv_weight(w_oihw, dt):
 
 
 def conv2d_nhwc(x, w_packed, ksize, stride, pad, scale=None, shift=None, residual=None, relu=False,
-                x2=None, up=1, stats=None, dt=DT_BF16):
+                x2=None, up=1, stats=None, dt=DT_BF16, tag="conv2d_fwd"):
     """K8.  x (B,H,W,Cx) NHWC in `dt`; x2 (B,H*up,W*up,C2) optional skip tensor
     (conv input = cat([x2, upsample(x, up)])).  Returns y (B,Ho,Wo,Cout) in `dt`."""
     tdt = _TORCH_DT[dt]
@@ -196,9 +237,10 @@ def conv2d_nhwc(x, w_packed, ksize, stride, pad, scale=None, shift=None, residua
         raise ValueError("residual must match the output")
     if stats is not None:
         _f32c(stats, "stats", (2 * Cout,))
-    N.check(N.lib().lss_conv2d_fwd(N.ptr(x), N.ptr(x2), N.ptr(w_packed), N.ptr(scale), N.ptr(shift),
-                                   N.ptr(residual), N.ptr(y), N.ptr(stats), B, H, W, Cx, C2, up, Cout,
-                                   KH, KW, stride, pad, 1 if relu else 0, dt, N.stream()), "lss_conv2d_fwd")
+    with _timed(tag):
+        N.check(N.lib().lss_conv2d_fwd(N.ptr(x), N.ptr(x2), N.ptr(w_packed), N.ptr(scale), N.ptr(shift),
+                                       N.ptr(residual), N.ptr(y), N.ptr(stats), B, H, W, Cx, C2, up, Cout,
+                                       KH, KW, stride, pad, 1 if relu else 0, dt, N.stream()), "lss_conv2d_fwd")
     return y
 
 
