@@ -91,17 +91,19 @@ int lss_geom_to_voxels(const float* geom, const float* dx, const float* bx, int 
 /* ---------------------------------------------------------------------------
  * K4  sort-free bucketing of points by voxel (replaces the argsort + gathers of
  *     src/model_BEV_TXT.py:110-111).
+ *   depth     (P) fp32 or NULL: per-point depth weight = K2's `depth` tensor, whose
+ *             flat index is the point id (NULL: weight 1, for pre-lifted inputs)
  *   vox_count (nvox) int32 in/out: per-voxel point counts on entry (from K3),
  *             all zero again on return (ready for the next call)
- *   vox_list  (nvox) int2 out: {start, len} of each voxel's slice of point_id
- *   point_id  (P) int32 out: point ids grouped by voxel; the order inside one
- *             voxel's slice is unspecified (K5 orders each slice by point id
- *             before summing, so the BEV sums are run-to-run reproducible)
+ *   vox_list  (nvox) int2 out: {start, len} of each voxel's slice of `entries`
+ *   entries   (P) int2 out: {point id, depth weight bits} grouped by voxel; the
+ *             order inside one voxel's slice is unspecified (K5 orders each
+ *             slice by point id before summing, so BEV sums are reproducible)
  *   cursor    (1) int32 in/out scratch, zero on entry, zero again on return
  */
-int lss_bucket_points(const int32_t* voxel, int P, int nvox, int32_t* vox_count,
-                      int32_t* vox_list /* nvox*2 */, int32_t* point_id,
-                      int32_t* cursor, void* stream);
+int lss_bucket_points(const int32_t* voxel, const float* depth, int P, int nvox,
+                      int32_t* vox_count, int32_t* vox_list /* nvox*2 */,
+                      int32_t* entries /* P*2 */, int32_t* cursor, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K2  CamEncode: 1x1 depthnet conv + softmax over the D depth logits.
@@ -118,16 +120,17 @@ int lss_depthnet_softmax_fwd(const float* x, const float* w, const float* bias,
                              float* depth, float* feat, int math, void* stream);
 
 /* ---------------------------------------------------------------------------
- * K5/K6  fused lift + splat: bev[v, c] = sum_{p in voxel v} depth[p] * feat[row(p), c]
+ * K5/K6  fused lift + splat: bev[v, c] = sum_{p in voxel v} w[p] * feat[row(p), c]
+ *        (w = the depth weight K4 stored next to the point id)
  * replaces: src/modules.py:84 (outer product), src/model_BEV_TXT.py:80,89
  *           (permute/reshape copy), :110-111 (gathers), src/tools.py:195-200
  *           (cumsum trick), src/model_BEV_TXT.py:120-124 (zeros, index_put, cat).
  * Every BEV element is written exactly once (zeros for empty voxels).
  *   C in {64, 128}; layout = LSS_BEV_*
  */
-int lss_lift_splat_fwd(const float* depth, const float* feat, const int32_t* vox_list,
-                       const int32_t* point_id, int B, int N, int D, int fH, int fW,
-                       int C, int X, int Y, int Z, void* bev, int layout, void* stream);
+int lss_lift_splat_fwd(const float* feat, const int32_t* vox_list, const int32_t* entries,
+                       int B, int N, int D, int fH, int fW, int C, int X, int Y, int Z,
+                       void* bev, int layout, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K7  backward of K5/K6 (+ softmax backward), point-stationary gather, no atomics.

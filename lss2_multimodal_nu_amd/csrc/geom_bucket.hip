@@ -103,15 +103,18 @@ __global__ __launch_bounds__(256) void geom_to_voxels_kernel(const float* __rest
   voxel[p] = v;
 }
 
-// One wave per 64 voxels: wave-scan the counts, reserve the tile's slice of
-// point_id with ONE atomic on the cursor (tile order in point_id is arbitrary,
-// every voxel's slice is contiguous).
-__global__ __launch_bounds__(256) void bucket_alloc_kernel(const int32_t* __restrict__ vox_count,
-                                                           int nvox, int32_t* __restrict__ vox_list,
-                                                           int32_t* __restrict__ cursor) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  const int v = wave * 64 + lane;
+// One 1024-thread workgroup per 1024 voxels: scan the counts (wave scan + LDS over
+// the 16 wave totals) and reserve the group's slice of the entry list with ONE
+// atomic on the cursor.  Group order in the list is arbitrary; inside a group
+// the voxels' slices are contiguous and in voxel order, which is what lets K5
+// stream a wave's 8 consecutive voxels as one contiguous range.
+__global__ __launch_bounds__(1024) void bucket_alloc_kernel(const int32_t* __restrict__ vox_count,
+                                                            int nvox, int32_t* __restrict__ vox_list,
+                                                            int32_t* __restrict__ cursor) {
+  __shared__ int wave_tot[16];
+  __shared__ int group_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int v = blockIdx.x * 1024 + threadIdx.x;
   const int c = (v < nvox) ? vox_count[v] : 0;
   int incl = c;
 #pragma unroll
@@ -119,32 +122,43 @@ __global__ __launch_bounds__(256) void bucket_alloc_kernel(const int32_t* __rest
     int t = __shfl_up(incl, o, 64);
     if (lane >= o) incl += t;
   }
-  const int total = __shfl(incl, 63, 64);
-  int base = 0;
-  if (total > 0) {
-    if (lane == 0) base = atomicAdd(cursor, total);
-    base = __shfl(base, 0, 64);
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = wave_tot[i];
+      wave_tot[i] = run;
+      run += t;
+    }
+    group_base = run > 0 ? atomicAdd(cursor, run) : 0;
   }
+  __syncthreads();
   if (v < nvox) {
-    vox_list[2 * v + 0] = base + incl - c;
+    vox_list[2 * v + 0] = group_base + wave_tot[wave] + incl - c;
     vox_list[2 * v + 1] = c;
   }
 }
 
 // One thread per point: take a slot of the voxel's slice by counting the voxel's
-// counter back down to zero (so vox_count is all-zero again for the next call).
+// counter back down to zero (so vox_count is all-zero again for the next call) and
+// write the list entry {point id, depth weight}: K5 then needs no dependent
+// depth load.
 __global__ __launch_bounds__(256) void bucket_fill_kernel(const int32_t* __restrict__ voxel, int P,
+                                                          const float* __restrict__ depth,
                                                           int32_t* __restrict__ vox_count,
                                                           const int32_t* __restrict__ vox_list,
-                                                          int32_t* __restrict__ point_id,
+                                                          int2* __restrict__ entries,
                                                           int32_t* __restrict__ cursor) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p == 0) *cursor = 0;  // alloc (previous kernel on the stream) is done with it
   if (p >= P) return;
   const int v = voxel[p];
   if (v < 0) return;
+  const float w = depth ? depth[p] : 1.0f;  // depth is (BN, D, HW): flat index == point id
   const int slot = atomicSub(vox_count + v, 1) - 1;
-  point_id[vox_list[2 * v] + slot] = p;
+  entries[vox_list[2 * v] + slot] = make_int2(p, __builtin_bit_cast(int, w));
 }
 
 // API-compat segmented sum (QuickCumsum.forward): one wave per run, lane = channel.
@@ -201,16 +215,18 @@ extern "C" int lss_geom_to_voxels(const float* geom, const float* dx, const floa
   return lss_launch_status();
 }
 
-extern "C" int lss_bucket_points(const int32_t* voxel, int P, int nvox, int32_t* vox_count,
-                                 int32_t* vox_list, int32_t* point_id, int32_t* cursor,
-                                 void* stream) {
+extern "C" int lss_bucket_points(const int32_t* voxel, const float* depth, int P, int nvox,
+                                 int32_t* vox_count, int32_t* vox_list, int32_t* entries,
+                                 int32_t* cursor, void* stream) {
   LSS_CHECK_PTR(voxel); LSS_CHECK_PTR(vox_count); LSS_CHECK_PTR(vox_list);
-  LSS_CHECK_PTR(point_id); LSS_CHECK_PTR(cursor);
+  LSS_CHECK_PTR(entries); LSS_CHECK_PTR(cursor);
   LSS_CHECK_POS(P); LSS_CHECK_POS(nvox);
-  hipLaunchKernelGGL(bucket_alloc_kernel, dim3(lss_cdiv(nvox, 256)), dim3(256), 0,
+  if ((reinterpret_cast<uintptr_t>(entries) & 7) != 0) return LSS_E_ALIGN;
+  hipLaunchKernelGGL(bucket_alloc_kernel, dim3(lss_cdiv(nvox, 1024)), dim3(1024), 0,
                      lss_stream(stream), vox_count, nvox, vox_list, cursor);
   hipLaunchKernelGGL(bucket_fill_kernel, dim3(lss_cdiv(P, 256)), dim3(256), 0,
-                     lss_stream(stream), voxel, P, vox_count, vox_list, point_id, cursor);
+                     lss_stream(stream), voxel, P, depth, vox_count, vox_list,
+                     reinterpret_cast<int2*>(entries), cursor);
   return lss_launch_status();
 }
 

@@ -1,69 +1,62 @@
 // K5/K6: fused lift + splat forward, and K7: its backward.
 //
-// Forward (output-stationary, atomic-free): a 256-thread workgroup owns a tile of
-// 64 consecutive BEV cells of one sample (one z-slab); each of its 4 waves sums 16
+// Forward (output-stationary, atomic-free): a 512-thread workgroup owns a tile of
+// 64 consecutive BEV cells of one sample (one z-slab); each of its 8 waves sums 8
 // of them with lane = channel:
-//     acc[c] = sum_{p in voxel} depth[p] * feat[row(p), c]
-// The voxel's point list is loaded 64 ids at a time (one per lane), ordered by
-// point id inside the wave (rank sort over readlanes -> the fp32 sum order is
-// fixed, results are run-to-run reproducible for lists <= 64 points), each
-// lane fetches the depth weight of ITS point, and the sum loop broadcasts
-// (row, depth) with v_readlane while the 256-B feature row load is coalesced.
-// The 64 x C tile is staged in LDS and written once: zeros for empty voxels
-// included, so there is no memset and every BEV byte is stored exactly once, in
-// 16-B-per-lane stores (NHWC) or 256-B channel-plane segments (NCHW).
+//     acc[c] = sum_{p in voxel} w[p] * feat[row(p), c]
+// K4 lays the entry lists of consecutive voxels out back to back, so a wave
+// streams its 8 voxels as ONE contiguous range of {point id, depth weight}
+// entries, 64 at a time (one per lane, whole voxels per chunk): the entries of a
+// chunk are ordered by point id inside each voxel (rank sort over ds_bpermute ->
+// the fp32 summation order is fixed, results are run-to-run reproducible), then
+// the sum loop broadcasts (row, weight) with v_readlane while the 256-B feature
+// row loads - 16 in flight per lane - are coalesced.  The 64 x C tile is staged in
+// LDS and written once, zeros for empty voxels included: no memset, no atomics,
+// every BEV byte stored exactly once, in 16-B-per-lane stores (NHWC) or 256-B
+// channel-plane segments (NCHW).
 //
 // The lifted (B,N,D,fH,fW,C) tensor of the reference (src/modules.py:84,
-// src/model_BEV_TXT.py:80,89) exists only as `depth * feat` in registers.
+// src/model_BEV_TXT.py:80,89) exists only as `w * feat` in registers.
 #include "lss_common.h"
 
 namespace {
 
 constexpr int TILE = 64;  // BEV cells per workgroup
+constexpr int NV = 8;     // voxels per wave
+constexpr int NWAVE = TILE / NV;
 
-template <int CPL /* channels per lane: C = 64*CPL */>
-__device__ __forceinline__ void sum_voxel(const float* __restrict__ depth,
-                                          const float* __restrict__ feat,
-                                          const int32_t* __restrict__ point_id, int start, int len,
+__device__ __forceinline__ float rl_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// Generic per-voxel path (lists longer than one chunk, or slices that are not
+// back to back): 64 entries at a time, ordered inside the chunk only.
+template <int CPL>
+__device__ __forceinline__ void sum_voxel(const float* __restrict__ feat,
+                                          const int2* __restrict__ entries, int start, int len,
                                           int DHW, int HW, int lane, float (&acc)[CPL]) {
   constexpr int C = 64 * CPL;
   for (int base = 0; base < len; base += 64) {
     const int n = min(64, len - base);
     int pid = 0x7fffffff;
-    if (lane < n) pid = point_id[start + base + lane];
+    float dep = 0.f;
+    if (lane < n) {
+      const int2 en = entries[start + base + lane];
+      pid = en.x;
+      dep = __builtin_bit_cast(float, en.y);
+    }
     if (n > 1) {
-      // rank sort: ids are distinct, so ranks are a permutation of 0..n-1
       int rank = 0;
       for (int jj = 0; jj < n; ++jj) rank += (__builtin_amdgcn_readlane(pid, jj) < pid) ? 1 : 0;
-      // push each id to the lane of its rank (lanes >= n keep INT_MAX: rank >= n)
-      pid = __builtin_amdgcn_ds_permute(min(rank, 63) << 2, pid);
+      const int dest = (lane < n ? rank : lane) << 2;
+      pid = __builtin_amdgcn_ds_permute(dest, pid);
+      dep = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dest, __builtin_bit_cast(int, dep)));
     }
-    float dep = 0.f;
     int row = 0;
-    if (lane < n) {
-      dep = depth[pid];  // depth is (BN, D, HW): its flat index IS the point id
-      const int bn = pid / DHW;
-      row = bn * HW + (pid % HW);
-    }
-    int i = 0;
-    for (; i + 4 <= n; i += 4) {
-      float f[4][CPL];
-      float dd[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int r = __builtin_amdgcn_readlane(row, i + u);
-        dd[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dep), i + u));
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) f[u][q] = feat[(size_t)r * C + q * 64 + lane];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) acc[q] = fmaf(dd[u], f[u][q], acc[q]);
-    }
-    for (; i < n; ++i) {
+    if (lane < n) row = (pid / DHW) * HW + (pid % HW);
+    for (int i = 0; i < n; ++i) {
       const int r = __builtin_amdgcn_readlane(row, i);
-      const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dep), i));
+      const float dd = rl_f(dep, i);
 #pragma unroll
       for (int q = 0; q < CPL; ++q) acc[q] = fmaf(dd, feat[(size_t)r * C + q * 64 + lane], acc[q]);
     }
@@ -72,10 +65,9 @@ __device__ __forceinline__ void sum_voxel(const float* __restrict__ depth,
 
 // grid = (tiles_per_sample, Z, B).  LAYOUT = LSS_BEV_*.
 template <int CPL, int LAYOUT>
-__global__ __launch_bounds__(256) void lift_splat_fwd_kernel(
-    const float* __restrict__ depth, const float* __restrict__ feat,
-    const int32_t* __restrict__ vox_list, const int32_t* __restrict__ point_id, int DHW, int HW,
-    int XY, int Z, void* __restrict__ bev_) {
+__global__ __launch_bounds__(512) void lift_splat_fwd_kernel(
+    const float* __restrict__ feat, const int32_t* __restrict__ vox_list,
+    const int2* __restrict__ entries, int DHW, int HW, int XY, int Z, void* __restrict__ bev_) {
   constexpr int C = 64 * CPL;
   // row stride: +4 keeps 16-B alignment for the NHWC b128 reads; +1 spreads the
   // column reads of the NCHW store over banks
@@ -85,35 +77,127 @@ __global__ __launch_bounds__(256) void lift_splat_fwd_kernel(
   const int cell0 = blockIdx.x * TILE;
   const int iz = blockIdx.y, b = blockIdx.z;
   const int ncell = min(TILE, XY - cell0);
+  float* my_rows = tile + wave * NV * LD;
 
-  // (start, len) of this wave's 16 voxels: one per lane (lanes 0..15)
+  // {start, len} of this wave's NV voxels: one per lane (lanes 0..NV-1)
   int my_start = 0, my_len = 0;
   {
-    const int jc = wave * 16 + lane;
-    if (lane < 16 && jc < ncell) {
+    const int jc = wave * NV + lane;
+    if (lane < NV && jc < ncell) {
       const size_t v = ((size_t)b * XY + cell0 + jc) * Z + iz;
       my_start = vox_list[2 * v];
       my_len = vox_list[2 * v + 1];
     }
   }
-  for (int s = 0; s < 16; ++s) {
-    const int len = __builtin_amdgcn_readlane(my_len, s);
-    float acc[CPL];
+  int pre_end = my_len;  // inclusive scan over lanes 0..NV-1
 #pragma unroll
-    for (int q = 0; q < CPL; ++q) acc[q] = 0.f;
-    if (len > 0) {
-      const int start = __builtin_amdgcn_readlane(my_start, s);
-      sum_voxel<CPL>(depth, feat, point_id, start, len, DHW, HW, lane, acc);
+  for (int o = 1; o < NV; o <<= 1) {
+    const int t = __shfl_up(pre_end, o, 64);
+    if (lane >= o) pre_end += t;
+  }
+  const int pre = pre_end - my_len;
+  const int total = __builtin_amdgcn_readlane(pre_end, NV - 1);
+
+  float acc[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) acc[q] = 0.f;
+  auto flush = [&](int slot) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      my_rows[slot * LD + q * 64 + lane] = acc[q];
+      acc[q] = 0.f;
     }
+  };
+
+  if (total == 0) {
+    for (int k = 0; k < NV; ++k) flush(k);
+  } else {
+    // are the non-empty slices back to back (same K4 group)?
+    const unsigned long long nonempty = __ballot(lane < NV && my_len > 0);
+    const int f0 = __builtin_ctzll(nonempty);
+    const int base = __builtin_amdgcn_readlane(my_start - pre, f0);
+    const bool ok = !(lane < NV && my_len > 0) || (my_start - pre == base);
+    if (__ballot(ok) != ~0ull) {
+      for (int k = 0; k < NV; ++k) {
+        const int len = __builtin_amdgcn_readlane(my_len, k);
+        if (len > 0) sum_voxel<CPL>(feat, entries, __builtin_amdgcn_readlane(my_start, k), len, DHW, HW, lane, acc);
+        flush(k);
+      }
+    } else {
+      int s = 0;
+      while (s < NV) {
+        const int off = __builtin_amdgcn_readlane(pre, s);
+        // whole voxels s..e-1 that fit one 64-entry chunk
+        const int cnt = __builtin_popcountll(__ballot(lane >= s && lane < NV && (pre_end - off) <= 64));
+        if (cnt == 0) {  // voxel s alone is longer than a chunk
+          sum_voxel<CPL>(feat, entries, base + off, __builtin_amdgcn_readlane(my_len, s), DHW, HW, lane, acc);
+          flush(s);
+          ++s;
+          continue;
+        }
+        const int e = s + cnt;
+        const int n = __builtin_amdgcn_readlane(pre_end, e - 1) - off;
+        int cur = s;
+        if (n > 0) {
+          int pid = 0x7fffffff;
+          float dep = 0.f;
+          if (lane < n) {
+            const int2 en = entries[base + off + lane];
+            pid = en.x;
+            dep = __builtin_bit_cast(float, en.y);
+          }
+          // voxel slot of every entry (entries are grouped by voxel, in voxel order)
+          int slot = s, maxlen = 0;
+          for (int i = s; i < e; ++i) {
+            if (i < e - 1) slot += (lane >= __builtin_amdgcn_readlane(pre_end, i) - off) ? 1 : 0;
+            maxlen = max(maxlen, __builtin_amdgcn_readlane(my_len, i));
+          }
+          if (maxlen > 1) {
+            const int first = __shfl(pre, slot, 64) - off;
+            const int vlen = __shfl(my_len, slot, 64);
+            int rank = 0;
+            for (int t = 0; t < maxlen; ++t) {
+              const int other = __shfl(pid, min(first + t, 63), 64);
+              rank += (t < vlen && other < pid) ? 1 : 0;
+            }
+            const int dest = (lane < n ? first + rank : lane) << 2;
+            pid = __builtin_amdgcn_ds_permute(dest, pid);
+            dep = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dest, __builtin_bit_cast(int, dep)));
+          }
+          int row = 0;  // lanes >= n: row 0 with weight 0 -> harmless loads
+          if (lane < n) row = (pid / DHW) * HW + (pid % HW);
+          for (int i0 = 0; i0 < n; i0 += 16) {
+            float f[16][CPL];
 #pragma unroll
-    for (int q = 0; q < CPL; ++q) tile[(wave * 16 + s) * LD + q * 64 + lane] = acc[q];
+            for (int u = 0; u < 16; ++u) {
+              const int r = __builtin_amdgcn_readlane(row, min(i0 + u, 63));
+#pragma unroll
+              for (int q = 0; q < CPL; ++q) f[u][q] = feat[(size_t)r * C + q * 64 + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              const int i = i0 + u;
+              if (i < n) {
+                const int sl = __builtin_amdgcn_readlane(slot, i);
+                while (cur < sl) flush(cur++);
+                const float dd = rl_f(dep, i);
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) acc[q] = fmaf(dd, f[u][q], acc[q]);
+              }
+            }
+          }
+        }
+        while (cur < e) flush(cur++);
+        s = e;
+      }
+    }
   }
   __syncthreads();
 
   if (LAYOUT == LSS_BEV_NHWC_F32) {
     float* bev = reinterpret_cast<float*>(bev_);
     // row of cell j: ((b*XY + cell0 + j)*Z + iz) * C ; 16 B per lane
-    for (int e = tid; e < TILE * (C / 4); e += 256) {
+    for (int e = tid; e < TILE * (C / 4); e += 512) {
       const int j = e / (C / 4), c4 = e % (C / 4);
       if (j < ncell) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(&tile[j * LD + c4 * 4]);
@@ -122,7 +206,7 @@ __global__ __launch_bounds__(256) void lift_splat_fwd_kernel(
     }
   } else if (LAYOUT == LSS_BEV_NHWC_BF16) {
     unsigned short* bev = reinterpret_cast<unsigned short*>(bev_);
-    for (int e = tid; e < TILE * (C / 8); e += 256) {
+    for (int e = tid; e < TILE * (C / 8); e += 512) {
       const int j = e / (C / 8), c8 = e % (C / 8);
       if (j < ncell) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(&tile[j * LD + c8 * 8]);
@@ -137,7 +221,7 @@ __global__ __launch_bounds__(256) void lift_splat_fwd_kernel(
     float* bev = reinterpret_cast<float*>(bev_);
     const bool vec_ok = (ncell == TILE) && ((XY & 3) == 0);
     if (vec_ok) {
-      for (int e = tid; e < C * (TILE / 4); e += 256) {
+      for (int e = tid; e < C * (TILE / 4); e += 512) {
         const int c = e / (TILE / 4), j4 = e % (TILE / 4);
         f32x4 v;
 #pragma unroll
@@ -145,7 +229,7 @@ __global__ __launch_bounds__(256) void lift_splat_fwd_kernel(
         *reinterpret_cast<f32x4*>(bev + (((size_t)b * Z + iz) * C + c) * XY + cell0 + j4 * 4) = v;
       }
     } else {
-      for (int e = tid; e < C * TILE; e += 256) {
+      for (int e = tid; e < C * TILE; e += 512) {
         const int c = e / TILE, j = e % TILE;
         if (j < ncell) bev[(((size_t)b * Z + iz) * C + c) * XY + cell0 + j] = tile[j * LD + c];
       }
@@ -242,23 +326,24 @@ __global__ __launch_bounds__(256) void lift_splat_bwd_kernel(
 
 }  // namespace
 
-extern "C" int lss_lift_splat_fwd(const float* depth, const float* feat, const int32_t* vox_list,
-                                  const int32_t* point_id, int B, int N, int D, int fH, int fW,
-                                  int C, int X, int Y, int Z, void* bev, int layout, void* stream) {
-  LSS_CHECK_PTR(depth); LSS_CHECK_PTR(feat); LSS_CHECK_PTR(vox_list); LSS_CHECK_PTR(point_id);
-  LSS_CHECK_PTR(bev);
+extern "C" int lss_lift_splat_fwd(const float* feat, const int32_t* vox_list, const int32_t* entries,
+                                  int B, int N, int D, int fH, int fW, int C, int X, int Y, int Z,
+                                  void* bev, int layout, void* stream) {
+  LSS_CHECK_PTR(feat); LSS_CHECK_PTR(vox_list); LSS_CHECK_PTR(entries); LSS_CHECK_PTR(bev);
   LSS_CHECK_POS(B); LSS_CHECK_POS(N); LSS_CHECK_POS(D); LSS_CHECK_POS(fH); LSS_CHECK_POS(fW);
   LSS_CHECK_POS(X); LSS_CHECK_POS(Y); LSS_CHECK_POS(Z);
   if (C != 64 && C != 128) return LSS_E_SHAPE;
   if (layout < 0 || layout > 2) return LSS_E_LAYOUT;
   if (B > 65535 || Z > 65535) return LSS_E_SHAPE;
-  if ((reinterpret_cast<uintptr_t>(bev) & 15) != 0) return LSS_E_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(bev) & 15) != 0 || (reinterpret_cast<uintptr_t>(entries) & 7) != 0)
+    return LSS_E_ALIGN;
   const int HW = fH * fW, DHW = D * HW, XY = X * Y;
   dim3 grid(lss_cdiv(XY, TILE), Z, B);
   hipStream_t st = lss_stream(stream);
+  const int2* en = reinterpret_cast<const int2*>(entries);
 #define LSS_FWD(CPL, LAY)                                                                      \
-  hipLaunchKernelGGL((lift_splat_fwd_kernel<CPL, LAY>), grid, dim3(256), 0, st, depth, feat,   \
-                     vox_list, point_id, DHW, HW, XY, Z, bev)
+  hipLaunchKernelGGL((lift_splat_fwd_kernel<CPL, LAY>), grid, dim3(512), 0, st, feat, vox_list, \
+                     en, DHW, HW, XY, Z, bev)
   if (C == 64) {
     if (layout == LSS_BEV_NCHW_F32) LSS_FWD(1, LSS_BEV_NCHW_F32);
     else if (layout == LSS_BEV_NHWC_F32) LSS_FWD(1, LSS_BEV_NHWC_F32);

@@ -51,7 +51,8 @@ class _LiftSplatFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, ws, dims, nx, math, layout):
         B, N, D, fH, fW, C = dims
         depth, feat = ops.depthnet_softmax(x.contiguous(), weight, bias, D, C, math)
-        bev = ops.lift_splat_fwd(depth, feat, ws, dims, nx, layout)
+        ops.bucket_points(ws, depth)
+        bev = ops.lift_splat_fwd(feat, ws, dims, nx, layout)
         ctx.save_for_backward(x, weight, depth, feat, ws.voxel.clone())
         ctx.dims, ctx.nx = dims, nx
         return bev
@@ -78,8 +79,7 @@ class _VoxelPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xflat, ws, B, nx, C):
         P = xflat.shape[0]
-        ones = torch.ones(P, dtype=torch.float32, device=xflat.device)
-        bev = ops.lift_splat_fwd(ones, xflat, ws, (B, P // B, 1, 1, 1, C), nx, ops.BEV_NCHW_F32)
+        bev = ops.lift_splat_fwd(xflat, ws, (B, P // B, 1, 1, 1, C), nx, ops.BEV_NCHW_F32)
         ctx.save_for_backward(ws.voxel.clone())
         ctx.shape = (B, nx, C)
         return bev
@@ -212,14 +212,14 @@ class _LiftSplatMixin:
             raise RuntimeError("feature map %dx%d does not match the frustum %s"
                                % (fH, fW, tuple(self.frustum.shape[:3])))
         ws, _ = self._index_points(rots, trans, intrins, post_rots, post_trans)
-        ops.bucket_points(ws)
         dims = (B, BN // B, self.D, fH, fW, self.camC)
         ce = self.camencode
         if _needs_autograd(ce, x):
             return _LiftSplatFn.apply(x.float(), ce.depthnet.weight, ce.depthnet.bias, ws, dims,
                                       self._nx_ints(), _PRECISIONS[ce.math], layout)
         depth, feat = ce.depth_and_context(x)
-        return ops.lift_splat_fwd(depth, feat, ws, dims, self._nx_ints(), layout)
+        ops.bucket_points(ws, depth)
+        return ops.lift_splat_fwd(feat, ws, dims, self._nx_ints(), layout)
 
     def get_voxels(self, x, rots, trans, intrins, post_rots, post_trans):
         return self._lift_splat(x, rots, trans, intrins, post_rots, post_trans, ops.BEV_NCHW_F32)

@@ -70,7 +70,7 @@ class SplatWorkspace:
         self.voxel = torch.empty(P, dtype=torch.int32, device=device)
         self.vox_count = torch.zeros(nvox, dtype=torch.int32, device=device)
         self.vox_list = torch.empty(nvox, 2, dtype=torch.int32, device=device)
-        self.point_id = torch.empty(P, dtype=torch.int32, device=device)
+        self.entries = torch.empty(P, 2, dtype=torch.int32, device=device)  # {point id, depth weight}
         self.cursor = torch.zeros(1, dtype=torch.int32, device=device)
 
 
@@ -113,10 +113,15 @@ def geom_to_voxels(geom, dx, bx, nx, B, ws, histogram=True):
             "lss_geom_to_voxels")
 
 
-def bucket_points(ws):
-    """K4 on a workspace whose voxel/vox_count were filled by K3."""
-    N.check(N.lib().lss_bucket_points(N.ptr(ws.voxel), ws.P, ws.nvox, N.ptr(ws.vox_count),
-                                      N.ptr(ws.vox_list), N.ptr(ws.point_id), N.ptr(ws.cursor),
+def bucket_points(ws, depth=None):
+    """K4 on a workspace whose voxel/vox_count were filled by K3.  `depth` = K2's
+    (BN,D,fH,fW) tensor (its flat index is the point id); None = unit weights."""
+    if depth is not None:
+        _f32c(depth, "depth")
+        if depth.numel() != ws.P:
+            raise ValueError("depth has %d elements, workspace has %d points" % (depth.numel(), ws.P))
+    N.check(N.lib().lss_bucket_points(N.ptr(ws.voxel), N.ptr(depth), ws.P, ws.nvox, N.ptr(ws.vox_count),
+                                      N.ptr(ws.vox_list), N.ptr(ws.entries), N.ptr(ws.cursor),
                                       N.stream()), "lss_bucket_points")
 
 
@@ -136,18 +141,18 @@ def depthnet_softmax(x, weight, bias, D, C, math=DT_F32):
     return depth, feat
 
 
-def lift_splat_fwd(depth, feat, ws, dims, nx, layout=BEV_NCHW_F32, tag="lift_splat_fwd"):
-    """K5/K6.  dims = (B,N,D,fH,fW,C).  Returns the BEV tensor with LOGICAL shape
+def lift_splat_fwd(feat, ws, dims, nx, layout=BEV_NCHW_F32, tag="lift_splat_fwd"):
+    """K5/K6 on a bucketed workspace (depth weights already sit in ws.entries).
+    dims = (B,N,D,fH,fW,C).  Returns the BEV tensor with LOGICAL shape
     (B, Z*C, X, Y): contiguous for NCHW_F32, channels_last strides for NHWC_*."""
     B, Ncam, D, fH, fW, C = dims
     X, Y, Z = nx
-    _f32c(depth, "depth")
     _f32c(feat, "feat")
-    if depth.numel() != B * Ncam * D * fH * fW or feat.numel() != B * Ncam * fH * fW * C:
-        raise ValueError("depth/feat size does not match dims %s" % (dims,))
-    if ws.P != depth.numel() or ws.nvox != B * X * Y * Z:
+    if feat.numel() != B * Ncam * fH * fW * C:
+        raise ValueError("feat size does not match dims %s" % (dims,))
+    if ws.P != B * Ncam * D * fH * fW or ws.nvox != B * X * Y * Z:
         raise ValueError("workspace does not match dims")
-    dev = depth.device
+    dev = feat.device
     if layout == BEV_NCHW_F32:
         bev = torch.empty(B, Z * C, X, Y, dtype=torch.float32, device=dev)
         out = bev
@@ -156,7 +161,7 @@ def lift_splat_fwd(depth, feat, ws, dims, nx, layout=BEV_NCHW_F32, tag="lift_spl
         bev = torch.empty(B, X, Y, Z * C, dtype=dt, device=dev)
         out = bev.permute(0, 3, 1, 2)
     with _timed(tag):
-        N.check(N.lib().lss_lift_splat_fwd(N.ptr(depth), N.ptr(feat), N.ptr(ws.vox_list), N.ptr(ws.point_id),
+        N.check(N.lib().lss_lift_splat_fwd(N.ptr(feat), N.ptr(ws.vox_list), N.ptr(ws.entries),
                                            B, Ncam, D, fH, fW, C, X, Y, Z, N.ptr(bev), layout, N.stream()),
                 "lss_lift_splat_fwd")
     return out

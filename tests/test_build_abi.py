@@ -44,8 +44,8 @@ def test_argument_checks_without_gpu(built):
     assert L.lss_points_to_voxels(None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 1, None, None, None, None) == -1
     assert L.lss_conv2d_packed_weight_bytes(4, 128, 1, 1, 1) == 4 * 128 * 2
     one = ctypes.c_void_p(16)
-    assert L.lss_lift_splat_fwd(one, one, one, one, 1, 1, 1, 1, 1, 48, 1, 1, 1, one, 0, None) == -2  # C not 64/128
-    assert L.lss_lift_splat_fwd(one, one, one, one, 1, 1, 1, 1, 1, 64, 1, 1, 1, one, 7, None) == -3  # bad layout
+    assert L.lss_lift_splat_fwd(one, one, one, 1, 1, 1, 1, 1, 48, 1, 1, 1, one, 0, None) == -2  # C not 64/128
+    assert L.lss_lift_splat_fwd(one, one, one, 1, 1, 1, 1, 1, 64, 1, 1, 1, one, 7, None) == -3  # bad layout
     assert L.lss_depthnet_softmax_fwd(one, one, one, 1, 100, 4, 4, 4, one, one, 0, None) == -2  # Cin % 64
 
 

@@ -86,8 +86,9 @@ def test_k4_bucketing(ops, golden, name):
         assert int(ws.vox_count.abs().sum()) == 0 and int(ws.cursor[0]) == 0
         voxel = ws.voxel.cpu().numpy()
         vl = ws.vox_list.cpu().numpy()
-        pid = ws.point_id.cpu().numpy()
+        pid = ws.entries.cpu().numpy()[:, 0]
         kept = np.flatnonzero(voxel >= 0)
+        assert np.all(ws.entries.cpu().numpy()[:kept.size, 1].copy().view(np.float32) == 1.0)  # no depth given
         cnt = np.bincount(voxel[kept], minlength=ws.nvox)
         assert np.array_equal(vl[:, 1], cnt)
         occ = np.flatnonzero(cnt)
@@ -160,10 +161,10 @@ def test_k5_lift_splat_small_vs_reference(ops, golden, name, layout):
     assert np.array_equal(geom.cpu().numpy(), g["geom"])
     vox_ref = np.where(g["cell"] >= 0, g["cell"] * Z + g["iz"], -1)
     assert np.array_equal(ws.voxel.cpu().numpy(), vox_ref)
-    ops.bucket_points(ws)
     depth, feat = ops.depthnet_softmax(dev(g["feat_in"]), dev(g["depthnet_weight"]), dev(g["depthnet_bias"]), D, C)
     np.testing.assert_allclose(depth.cpu().numpy(), g["depth"], rtol=2e-5, atol=1e-7)
-    bev = ops.lift_splat_fwd(depth, feat, ws, dims, (X, Y, Z), layout)
+    ops.bucket_points(ws, depth)
+    bev = ops.lift_splat_fwd(feat, ws, dims, (X, Y, Z), layout)
     assert tuple(bev.shape) == (B, Z * C, X, Y)
     out = bev.float().cpu().numpy()
     ref = g["out"]
@@ -187,11 +188,11 @@ def test_k5_full_size_vs_reference_stats(ops, golden, name, bsz):
     fr = lo.create_frustum((128, 352), 16, GRID_DEFAULT["dbound"])
     dxbxnx = lo.gen_dx_bx(GRID_DEFAULT["xbound"], GRID_DEFAULT["ybound"], GRID_DEFAULT["zbound"])
     ws, _ = run_k3(ops, g, fr, dxbxnx, want_geom=False)
-    ops.bucket_points(ws)
     depth, feat = ops.depthnet_softmax(feat_in.cuda(), dev(g["depthnet_weight"]), dev(g["depthnet_bias"]), D, C)
+    ops.bucket_points(ws, depth)
     outs = {}
     for layout in LAYOUTS:
-        outs[layout] = ops.lift_splat_fwd(depth, feat, ws, (B, N, D, fH, fW, C), (200, 200, 1), layout).float().cpu().numpy()
+        outs[layout] = ops.lift_splat_fwd(feat, ws, (B, N, D, fH, fW, C), (200, 200, 1), layout).float().cpu().numpy()
     assert np.array_equal(outs[0], outs[1])  # same sums, two layouts
     out = outs[0]
     occ = np.abs(out).sum(1) > 0
@@ -209,8 +210,8 @@ def test_k5_full_size_vs_reference_stats(ops, golden, name, bsz):
     # run-to-run reproducible (per-voxel sums are ordered by point id)
     ops.points_to_voxels(fr.cuda(), dev(g["inv_post_rots"]), dev(g["post_trans"]), dev(g["combine"]),
                          dev(g["trans"]), dxbxnx[0].cuda(), dxbxnx[1].cuda(), (200, 200, 1), ws)
-    ops.bucket_points(ws)
-    again = ops.lift_splat_fwd(depth, feat, ws, (B, N, D, fH, fW, C), (200, 200, 1), 0).cpu().numpy()
+    ops.bucket_points(ws, depth)
+    again = ops.lift_splat_fwd(feat, ws, (B, N, D, fH, fW, C), (200, 200, 1), 0).cpu().numpy()
     assert np.array_equal(again, out)
 
 
@@ -319,7 +320,7 @@ def test_k8_conv_vs_torch(ops, cfg, dt):
 def test_bad_arguments_raise(ops):
     ws = ops.SplatWorkspace(10, 10, "cuda")
     with pytest.raises(ValueError):
-        ops.lift_splat_fwd(torch.zeros(10, device="cuda"), torch.zeros(10, device="cuda"), ws, (1, 1, 1, 1, 10, 7), (10, 1, 1))
+        ops.lift_splat_fwd(torch.zeros(10, device="cuda"), ws, (1, 1, 1, 1, 10, 7), (10, 1, 1))
     with pytest.raises(ValueError):
         ops.depthnet_softmax(torch.zeros(1, 100, 2, 2, device="cuda"), torch.zeros(8, 100, device="cuda"),
                              torch.zeros(8, device="cuda"), 4, 4)
