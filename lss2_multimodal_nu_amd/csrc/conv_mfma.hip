@@ -56,6 +56,16 @@ struct Frag<float> {
   static constexpr int KBLOCK = 8;  // 2 halves x 1 piece (4 k-steps of 2)
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
+// vmcnt(0), which would expose the latency of the weight / patch prefetch loads
+// that are meant to stay in flight across it (cdna_hip_programming.md section 5,
+// "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ f32x4 lerp4(f32x4 a, f32x4 b, float t) {
   f32x4 r;
 #pragma unroll
@@ -229,23 +239,40 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
 //     gathered ONCE into LDS (the fused bilinear-upsample / concat gather runs
 //     here, once per element instead of once per tap) and re-used by all 9
 //     taps through shifted ds_read_b128 windows;
-//   * per (chunk, tap) step the BN x 64 weight slab is staged global -> registers
-//     -> LDS, double-buffered, the loads of step s+1 in flight behind the 16
-//     MFMAs of step s; one barrier per step.
-// LDS rows (one pixel position / one output channel = 64 bf16) are padded from
-// 128 to 144 B so the 16-lane groups of ds_read_b128 spread over all 64 banks.
+//   * per (chunk, tap) step the BN x 64 weight slab streams global -> LDS by
+//     LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) into a 3-slot ring,
+//     two steps ahead of the MFMAs; the step barrier is a raw s_barrier behind a
+//     COUNTED vmcnt, so the younger slab stays in flight across it.
+// LDS images: patch positions are 144 B apart (128 B of channels + 16 B pad) and
+// patch rows are padded to a multiple of 256 B, which makes the two pixel rows of a
+// 32-row MFMA tile land on complementary bank sets (conflict-free ds_read_b128);
+// weight rows are 128 B, XOR-swizzled by ((row >> 1) & 7) on the DMA's SOURCE
+// address (the DMA destination is lane-linear) and on the read address.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <int TH, int BN, bool FUSED>
 __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(ConvArgs a, int tilesX, int tilesY) {
-  constexpr int TW = 16, IW = TW + 2, IH = TH + 2, ROWB = 144;
-  constexpr int IN_BYTES = IH * IW * ROWB;
-  constexpr int W_BYTES = BN * ROWB;
-  constexpr int WPT = BN / 32;     // 16-B weight pieces per thread per step
-  constexpr int WCOLS = BN / 64;   // waves along the channel axis
-  __shared__ __attribute__((aligned(16))) unsigned char smem[IN_BYTES + 2 * W_BYTES];
-  unsigned char* in_tile = smem;
-  unsigned char* w_tile = smem + IN_BYTES;
+  constexpr int TW = 16, IW = TW + 2, IH = TH + 2, POSB = 144;
+  constexpr int IROWB = (IW * POSB + 255) / 256 * 256;  // 2816
+  constexpr int IN_BYTES = IH * IROWB;
+  constexpr int W_BYTES = BN * 128;
+  constexpr int WPT = BN / 32;    // LDS-DMA instructions per wave per step (1 KiB each)
+  constexpr int WCOLS = BN / 64;  // waves along the channel axis
+  constexpr int IPT = (IH * IW * 8 + 255) / 256;  // 16-B patch pieces per thread per chunk
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * W_BYTES + IN_BYTES];
+  unsigned char* w_tile = smem;
+  unsigned char* in_tile = smem + 3 * W_BYTES;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   int t = blockIdx.x;
   const int tx = t % tilesX; t /= tilesX;
@@ -255,11 +282,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(ConvArgs a, int til
   const int wc = wave % WCOLS, wr = wave / WCOLS;
   const int prow0 = wr * 4;
 
-  int aoff[2], boff[2];
+  int aoff[2], boff[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    aoff[i] = ((prow0 + 2 * i + (r >> 4)) * IW + (r & 15)) * ROWB + h * 64;
-    boff[i] = (wc * 64 + i * 32 + r) * ROWB + h * 64;
+    aoff[i] = (prow0 + 2 * i + (r >> 4)) * IROWB + (r & 15) * POSB + h * 64;
+    const int row = wc * 64 + i * 32 + r;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) boff[i][s4] = row * 128 + (((4 * h + s4) ^ ((row >> 1) & 7)) << 4);
   }
   f32x16 acc[2][2];
 #pragma unroll
@@ -271,63 +300,157 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(ConvArgs a, int til
 
   const unsigned short* wg = reinterpret_cast<const unsigned short*>(a.w);
   const int nsteps = (a.Cin / 64) * 9;
-  uint4 wreg[WPT];
-  auto load_w = [&](int step) {
+  uint4 ireg[IPT];
+  // weight slab of `step` -> ring slot: lane l of DMA block k lands at byte k*1024 + l*16,
+  // i.e. row 8k + (l >> 3), 16-B slot l & 7, which must hold channel piece slot ^ swz(row)
+  auto issue_w = [&](int step, int slot) {
     const int tap = step % 9, chunk = step / 9;
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
-      const int p = tid + i * 256;
-      const int row = p >> 3, part = p & 7;
-      const int co = n0 + row;
-      wreg[i] = make_uint4(0, 0, 0, 0);
-      if (co < a.Cout)
-        wreg[i] = *reinterpret_cast<const uint4*>(wg + ((size_t)tap * a.Cout + co) * a.Cin + chunk * 64 + part * 8);
+      const int blk = i * 4 + wave;
+      const int row = blk * 8 + (lane >> 3);
+      const int part = (lane & 7) ^ ((row >> 1) & 7);
+      const int co = min(n0 + row, a.Cout - 1);  // rows past Cout: any valid address (never stored)
+      glds16(wg + ((size_t)tap * a.Cout + co) * a.Cin + chunk * 64 + part * 8,
+             w_tile + slot * W_BYTES + blk * 1024);
     }
   };
-  load_w(0);
-
-  for (int step = 0; step < nsteps; ++step) {
-    const int tap = step % 9, chunk = step / 9;
-    if (tap == 0) {
-      if (step > 0) __syncthreads();  // every wave is done with the previous chunk's patch
+  // input patch of one 64-channel chunk.  !FUSED: plain 16-B loads, unrolled so they
+  // can be parked in registers (prefetch).  FUSED: the 4-corner bilinear gather goes
+  // straight to LDS piece by piece (rolled loop: keeps the live set small).
+  auto gather_in = [&](int chunk, bool to_lds) {
+    if (FUSED) {
+#pragma unroll 1
       for (int q = tid; q < IH * IW * 8; q += 256) {
         const int pos = q >> 3, part = q & 7;
         const int py = pos / IW, px = pos - py * IW;
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
-          v = load_in_piece<unsigned short, FUSED>(a, b, iy, ix, chunk * 64 + part * 8);
-        *reinterpret_cast<uint4*>(in_tile + pos * ROWB + part * 16) = v;
+          v = load_in_piece<unsigned short, true>(a, b, iy, ix, chunk * 64 + part * 8);
+        *reinterpret_cast<uint4*>(in_tile + py * IROWB + px * POSB + part * 16) = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < IPT; ++i) {
+        const int q = tid + i * 256;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q < IH * IW * 8) {
+          const int pos = q >> 3, part = q & 7;
+          const int py = pos / IW, px = pos - py * IW;
+          const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+          if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
+            v = load_in_piece<unsigned short, false>(a, b, iy, ix, chunk * 64 + part * 8);
+          if (to_lds) *reinterpret_cast<uint4*>(in_tile + py * IROWB + px * POSB + part * 16) = v;
+        }
+        if (!to_lds) ireg[i] = v;
       }
     }
-    unsigned char* wbuf = w_tile + (step & 1) * W_BYTES;
+  };
+  auto store_in = [&]() {
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int p = tid + i * 256;
-      *reinterpret_cast<uint4*>(wbuf + (p >> 3) * ROWB + (p & 7) * 16) = wreg[i];
+    for (int i = 0; i < IPT; ++i) {
+      const int q = tid + i * 256;
+      if (q < IH * IW * 8) {
+        const int pos = q >> 3, part = q & 7;
+        const int py = pos / IW, px = pos - py * IW;
+        *reinterpret_cast<uint4*>(in_tile + py * IROWB + px * POSB + part * 16) = ireg[i];
+      }
     }
-    __syncthreads();
-    if (step + 1 < nsteps) load_w(step + 1);
-    const int toff = ((tap / 3) * IW + (tap % 3)) * ROWB;
+  };
+
+  // one 1-KiB LDS-DMA block of the slab of `step` (block index i of this wave)
+  auto issue_w1 = [&](int tap, int chunk, int slot, int i) {
+    const int blk = i * 4 + wave;
+    const int row = blk * 8 + (lane >> 3);
+    const int part = (lane & 7) ^ ((row >> 1) & 7);
+    const int co = min(n0 + row, a.Cout - 1);
+    glds16(wg + ((size_t)tap * a.Cout + co) * a.Cin + chunk * 64 + part * 8,
+           w_tile + slot * W_BYTES + blk * 1024);
+  };
+  const int nchunks = a.Cin / 64;
+
+  // prologue: W(0), W(1) on their way; patch of chunk 0
+  issue_w(0, 0);
+  if (nsteps > 1) issue_w(1, 1);
+  gather_in(0, true);
+  wait_vmcnt<0>();
+  lds_barrier();
+
+  // Main loop.  9 taps fully unrolled, so ring slots (step % 3 == tap % 3) and the
+  // fragment double buffer (k-step parity) are static.  Rolling prefetch: while the 4
+  // MFMAs of one k-step run, the 2 A + 2 B fragments of the NEXT k-step are already
+  // in flight (32 fragment VGPRs in total), and one DMA block of the slab two steps
+  // ahead is issued per k-step, so LDS latency and DMA issue hide behind MFMAs.
+  bf16x8 fa[2][2], fb[2][2];  // [k-step parity][tile]
+  auto read_a = [&](int buf, int tap, int s4) {
+    const int toff = (tap / 3) * IROWB + (tap % 3) * POSB + s4 * 16;
+    fa[buf][0] = *reinterpret_cast<const bf16x8*>(in_tile + aoff[0] + toff);
+    fa[buf][1] = *reinterpret_cast<const bf16x8*>(in_tile + aoff[1] + toff);
+  };
+  auto read_b = [&](int buf, int tap, int s4) {
+    const unsigned char* wbuf = w_tile + (tap % 3) * W_BYTES;
+    fb[buf][0] = *reinterpret_cast<const bf16x8*>(wbuf + boff[0][s4]);
+    fb[buf][1] = *reinterpret_cast<const bf16x8*>(wbuf + boff[1][s4]);
+  };
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const bool last_chunk = chunk + 1 == nchunks;
+    read_a(0, 0, 0);
+    read_b(0, 0, 0);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(in_tile + aoff[0] + toff + s * 16);
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(in_tile + aoff[1] + toff + s * 16);
-      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wbuf + boff[0] + s * 16);
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wbuf + boff[1] + s * 16);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    for (int tap = 0; tap < 9; ++tap) {
+      // slab two steps ahead: tap+2 of this chunk, or tap+2-9 of the next one
+      const int t2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;
+      const int c2 = tap + 2 < 9 ? chunk : chunk + 1;
+      const bool more = c2 < nchunks;
+      const bool prefetch = !FUSED && tap == 5 && !last_chunk;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int cur = s4 & 1, nxt = cur ^ 1;
+        if (s4 < 3) {
+          read_a(nxt, tap, s4 + 1);
+          read_b(nxt, tap, s4 + 1);
+        } else if (tap < 8) {
+          read_a(nxt, tap + 1, 0);  // next tap's weights are only readable after the barrier
+        }
+        // keep the prefetch reads AHEAD of this k-step's MFMAs (hipcc's scheduler would
+        // otherwise sink them next to their use and expose the LDS latency again)
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
+        if (more && s4 < WPT) issue_w1(t2, c2, (tap + 2) % 3, s4);
+      }
+      if (prefetch) gather_in(chunk + 1, false);  // next patch -> registers
+      if (tap == 8 && !last_chunk) {
+        lds_barrier();  // every wave is done with this chunk's patch
+        if (FUSED) gather_in(chunk + 1, true);
+        else store_in();
+      }
+      // W(step+1) must have landed in every wave's share before anyone reads it; only the
+      // DMA (and patch loads) issued during THIS step may stay in flight
+      if (prefetch) wait_vmcnt<WPT + IPT>();
+      else if (more) wait_vmcnt<WPT>();
+      else wait_vmcnt<0>();
+      lds_barrier();
+      if (tap < 8) read_b(0, tap + 1, 0);
     }
   }
 
-  // epilogue: D[row = (i&3) + 8*(i>>2) + 4*h][col = r]; row -> pixel (row>>4, row&15) of the row tile
-  unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
-  const unsigned short* res = reinterpret_cast<const unsigned short*>(a.residual);
+  // epilogue.  D[row = (i&3) + 8*(i>>2) + 4*h][col = r]: a lane holds ONE output
+  // channel of 16 pixels, so storing from registers would be 2-B scattered stores.
+  // Instead: scale/shift in registers -> fp32 tile in LDS (the ring + patch area is
+  // free now) -> every thread picks up 8 consecutive channels of a pixel, adds the
+  // residual (one 16-B load), ReLU, rounds to bf16 once, and stores 16 B.
+  constexpr int OLD = BN + 4;  // fp32 row stride of the staged tile (16-B aligned rows)
+  static_assert(TH * 16 * OLD * 4 <= 3 * W_BYTES + IN_BYTES, "output tile must fit in LDS");
+  float* otile = reinterpret_cast<float*>(smem);
+  // (the loop's final lds_barrier already guarantees every wave is done reading LDS)
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
-    const int co = n0 + wc * 64 + ct * 32 + r;
+    const int cl = wc * 64 + ct * 32 + r;  // channel within the tile
+    const int co = n0 + cl;
     const bool cok = co < a.Cout;
     const float sc = (cok && a.scale) ? a.scale[co] : 1.f;
     const float sh = (cok && a.shift) ? a.shift[co] : 0.f;
@@ -337,16 +460,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(ConvArgs a, int til
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int oy = oy0 + prow0 + 2 * rt + (row >> 4), ox = ox0 + (row & 15);
-        if (cok && oy < a.Ho && ox < a.Wo) {
-          const float raw = acc[rt][ct][i];
-          s1 += raw;
-          s2 += raw * raw;
-          float v = raw * sc + sh;
-          const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
-          if (res) v += lss_bf2f(res[o]);
-          if (a.relu) v = fmaxf(v, 0.f);
-          y[o] = lss_f2bf(v);
+        const int pl = (prow0 + 2 * rt + (row >> 4)) * 16 + (row & 15);  // pixel within the tile
+        const float raw = acc[rt][ct][i];
+        otile[pl * OLD + cl] = raw * sc + sh;
+        if (a.stats) {
+          const int oy = oy0 + (pl >> 4), ox = ox0 + (pl & 15);
+          if (cok && oy < a.Ho && ox < a.Wo) {
+            s1 += raw;
+            s2 += raw * raw;
+          }
         }
       }
     }
@@ -356,6 +478,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(ConvArgs a, int til
       if (h == 0 && cok) {
         atomicAdd(a.stats + co, s1);
         atomicAdd(a.stats + a.Cout + co, s2);
+      }
+    }
+  }
+  lds_barrier();
+  unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
+  const unsigned short* res = reinterpret_cast<const unsigned short*>(a.residual);
+  const bool vec_ok = (a.Cout & 7) == 0;  // 16-B aligned channel groups
+  for (int e = tid; e < TH * 16 * (BN / 8); e += 256) {
+    const int pl = e / (BN / 8), c8 = e % (BN / 8);
+    const int oy = oy0 + (pl >> 4), ox = ox0 + (pl & 15);
+    const int co = n0 + c8 * 8;
+    if (oy >= a.Ho || ox >= a.Wo || co >= a.Cout) continue;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8 + 4);
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
+    if (vec_ok && co + 8 <= a.Cout) {
+      if (res) {
+        const uint4 rv = *reinterpret_cast<const uint4*>(res + o);
+        const unsigned int ru[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[2 * k] += lss_bf2f((unsigned short)(ru[k] & 0xffff));
+          v[2 * k + 1] += lss_bf2f((unsigned short)(ru[k] >> 16));
+        }
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+      }
+      uint4 ov;
+      ov.x = lss_pack_bf2(v[0], v[1]); ov.y = lss_pack_bf2(v[2], v[3]);
+      ov.z = lss_pack_bf2(v[4], v[5]); ov.w = lss_pack_bf2(v[6], v[7]);
+      *reinterpret_cast<uint4*>(y + o) = ov;
+    } else {
+      for (int k = 0; k < 8 && co + k < a.Cout; ++k) {
+        float t = v[k];
+        if (res) t += lss_bf2f(res[o + k]);
+        if (a.relu) t = fmaxf(t, 0.f);
+        y[o + k] = lss_f2bf(t);
       }
     }
   }

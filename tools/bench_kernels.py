@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark on one GPU: every BevEncode conv shape at batch B
+(bf16) and the L1 kernels, timed with HIP events on the launch stream.
+    python tools/bench_kernels.py [--batch 4] [--iters 30] [--only conv|l1]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lss2_multimodal_nu_amd import ops  # noqa: E402
+
+# name, H, W (of x), Cx, Cout, k, stride, pad, C2, up, residual
+CONVS = [
+    ("conv1 7x7/2", 200, 200, 64, 64, 7, 2, 3, 0, 1, False),
+    ("layer1 3x3", 100, 100, 64, 64, 3, 1, 1, 0, 1, True),
+    ("layer2.0.c1 3x3/2", 100, 100, 64, 128, 3, 2, 1, 0, 1, False),
+    ("layer2.0.ds 1x1/2", 100, 100, 64, 128, 1, 2, 0, 0, 1, False),
+    ("layer2 3x3", 50, 50, 128, 128, 3, 1, 1, 0, 1, True),
+    ("layer3.0.c1 3x3/2", 50, 50, 128, 256, 3, 2, 1, 0, 1, False),
+    ("layer3.0.ds 1x1/2", 50, 50, 128, 256, 1, 2, 0, 0, 1, False),
+    ("layer3 3x3", 25, 25, 256, 256, 3, 1, 1, 0, 1, True),
+    ("up1.conv0 up4+cat", 25, 25, 256, 256, 3, 1, 1, 64, 4, False),
+    ("up1.conv3 3x3", 100, 100, 256, 256, 3, 1, 1, 0, 1, False),
+    ("up2.1 up2", 100, 100, 256, 128, 3, 1, 1, 0, 2, False),
+    ("up2.4 1x1 head", 200, 200, 128, 4, 1, 1, 0, 0, 1, False),
+]
+COUNT = {"layer1 3x3": 4, "layer2 3x3": 3, "layer3 3x3": 3}
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    B, dt = args.batch, ops.DT_BF16
+    tot_us = tot_fl = 0.0
+    if args.only in ("", "conv"):
+        print("%-22s %10s %10s %8s" % ("conv (B=%d, bf16)" % B, "us", "GFLOP", "TFLOP/s"))
+        for name, H, W, Cx, Cout, k, st, pad, C2, up, res in CONVS:
+            x = torch.randn(B, H, W, Cx, device="cuda").to(torch.bfloat16)
+            x2 = torch.randn(B, H * up, W * up, C2, device="cuda").to(torch.bfloat16) if C2 else None
+            w = ops.pack_conv_weight(torch.randn(Cout, Cx + C2, k, k, device="cuda") * 0.05, dt)
+            sc, sh = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda")
+            Ho = (H * up + 2 * pad - k) // st + 1
+            Wo = (W * up + 2 * pad - k) // st + 1
+            r = torch.randn(B, Ho, Wo, Cout, device="cuda").to(torch.bfloat16) if res else None
+            us = timeit(lambda: ops.conv2d_nhwc(x, w, (k, k), st, pad, sc, sh, r, True, x2, up, None, dt), args.iters)
+            fl = 2.0 * B * Ho * Wo * Cout * (Cx + C2) * k * k
+            n = COUNT.get(name, 1)
+            tot_us += us * n
+            tot_fl += fl * n
+            print("%-22s %10.1f %10.2f %8.1f   x%d" % (name, us, fl / 1e9, fl / us / 1e6, n))
+        print("%-22s %10.1f %10.2f %8.1f" % ("BevEncode total", tot_us, tot_fl / 1e9, tot_fl / tot_us / 1e6))
+    if args.only in ("", "l1"):
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import lss_oracle as lo
+        D, C, fH, fW, N = 41, 64, 8, 22, 6
+        dx, bx, nx = lo.gen_dx_bx([-50.0, 50.0, 0.5], [-50.0, 50.0, 0.5], [-10.0, 10.0, 20.0])
+        fr = lo.create_frustum((128, 352), 16, [4.0, 45.0, 1.0]).cuda()
+        rots, trans, intr, prot, ptr = lo.synthetic_rig(B, train_aug=True, seed=0)
+        inv_pr, comb = lo.calib_matrices(rots, intr, prot)
+        g = [t.contiguous().cuda() for t in (inv_pr, ptr, comb, trans, dx, bx)]
+        x = torch.randn(B * N, 512, fH, fW, device="cuda")
+        w = torch.randn(D + C, 512, device="cuda") * 512 ** -0.5
+        b = torch.randn(D + C, device="cuda") * 0.1
+        ws = ops.SplatWorkspace(B * N * D * fH * fW, B * 200 * 200, "cuda")
+        depth, feat = ops.depthnet_softmax(x, w, b, D, C)
+
+        def k3():
+            ops.points_to_voxels(fr, g[0], g[1], g[2], g[3], g[4], g[5], (200, 200, 1), ws)
+
+        def k34():
+            k3()
+            ops.bucket_points(ws, depth)
+
+        k34()
+        print("%-28s %10s" % ("L1 kernel (B=%d)" % B, "us"))
+        t3 = timeit(k34, args.iters)
+        print("%-28s %10.1f" % ("K3+K4 (voxels,alloc,fill)", t3))
+        for math, nm in ((ops.DT_F32, "f32"), (ops.DT_BF16, "bf16")):
+            print("%-28s %10.1f" % ("K2 depthnet+softmax " + nm, timeit(lambda: ops.depthnet_softmax(x, w, b, D, C, math), args.iters)))
+        k34()
+        for lay, nm, nbytes in ((0, "NCHW f32", 4), (1, "NHWC f32", 4), (2, "NHWC bf16", 2)):
+            us = timeit(lambda: ops.lift_splat_fwd(feat, ws, (B, N, D, fH, fW, C), (200, 200, 1), lay), args.iters)
+            print("%-28s %10.1f   %7.0f GB/s written" % ("K5 lift-splat " + nm, us, B * 64 * 200 * 200 * nbytes / us / 1e3))
+        G = torch.randn(B, 200, 200, 64, device="cuda").permute(0, 3, 1, 2)
+        print("%-28s %10.1f" % ("K7 lift-splat bwd (NHWC G)", timeit(lambda: ops.lift_splat_bwd(G, ws.voxel, depth, feat, (B, N, D, fH, fW, C), (200, 200, 1)), args.iters)))
+
+
+if __name__ == "__main__":
+    main()
