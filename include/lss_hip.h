@@ -182,6 +182,19 @@ int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packed,
                    int Cout, int KH, int KW, int stride, int pad, int relu, int dt,
                    void* stream);
 
+/* Stride-2 convs (3x3 pad 1, 7x7 pad 3; bf16) on the LDS-tiled MFMA kernel: the
+ * conv is evaluated as a stride-1 conv over the 4 parity phases of the input
+ * (space-to-depth folded into the operand gather).  Weights are arranged
+ * [tap'][Cout][phase*Cin + ci] by lss_conv2d_pack_weights_s2d.  Same epilogue as
+ * lss_conv2d_fwd.  replaces: conv1 (src/modules.py:99) and the stride-2 convs of
+ * torchvision's layer2.0 / layer3.0. */
+size_t lss_conv2d_s2d_packed_weight_bytes(int Cout, int Cin, int K, int pad);
+int lss_conv2d_pack_weights_s2d(const float* w_oihw, int Cout, int Cin, int K, int pad,
+                                void* w_packed, void* stream);
+int lss_conv2d_s2_fwd(const void* x, const void* w_s2d, const float* scale, const float* shift,
+                      const void* residual, void* y, float* stats, int B, int H, int W, int Cx,
+                      int Cout, int K, int pad, int relu, void* stream);
+
 /* Layout / dtype conversion helpers between the reference's NCHW fp32 tensors
  * and the conv path's NHWC tensors. */
 int lss_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int dt,

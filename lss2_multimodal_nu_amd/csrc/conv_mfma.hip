@@ -258,16 +258,27 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TH, int BN, bool FUSED>
-__global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(ConvArgs a, int tilesX, int tilesY) {
-  constexpr int TW = 16, IW = TW + 2, IH = TH + 2, POSB = 144;
+// MODE 0: plain NHWC input, stride 1.  MODE 1: fused [x2 | bilinear-upsampled x] input.
+// MODE 2: stride-2 conv as a stride-1 conv over the 4 parity phases of the input
+// (space-to-depth done by the gather: chunk -> (phase, 64-channel block); weights
+// come pre-arranged as [tap'][co][phase*Cx + c] from lss_conv2d_pack_weights_s2d).
+// KH x KW = taps of the stride-1 problem, PAD = patch rows/cols before the output pixel.
+template <int TH, int BN, int MODE, int KH, int KW, int PAD>
+__global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX, int tilesY) {
+  constexpr bool FUSED = MODE == 1;
+  constexpr int NT = KH * KW;
+  constexpr int TW = 16, IW = TW + KW - 1, IH = TH + KH - 1, POSB = 144;
   constexpr int IROWB = (IW * POSB + 255) / 256 * 256;  // 2816
   constexpr int IN_BYTES = IH * IROWB;
   constexpr int W_BYTES = BN * 128;
   constexpr int WPT = BN / 32;    // LDS-DMA instructions per wave per step (1 KiB each)
   constexpr int WCOLS = BN / 64;  // waves along the channel axis
   constexpr int IPT = (IH * IW * 8 + 255) / 256;  // 16-B patch pieces per thread per chunk
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * W_BYTES + IN_BYTES];
+  constexpr int OLD = BN + 4;  // fp32 row stride of the epilogue's staged output tile
+  constexpr int OUT_BYTES = TH * 16 * OLD * 4;
+  constexpr int SMEM_BYTES = (3 * W_BYTES + IN_BYTES) > OUT_BYTES ? (3 * W_BYTES + IN_BYTES) : OUT_BYTES;
+  static_assert(SMEM_BYTES <= 80 * 1024, "two workgroups must fit one CU's 160 KiB of LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
   unsigned char* w_tile = smem;
   unsigned char* in_tile = smem + 3 * W_BYTES;
 
@@ -299,12 +310,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(ConvArgs a, int til
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const unsigned short* wg = reinterpret_cast<const unsigned short*>(a.w);
-  const int nsteps = (a.Cin / 64) * 9;
+  const int nsteps = (a.Cin / 64) * NT;
   uint4 ireg[IPT];
   // weight slab of `step` -> ring slot: lane l of DMA block k lands at byte k*1024 + l*16,
   // i.e. row 8k + (l >> 3), 16-B slot l & 7, which must hold channel piece slot ^ swz(row)
   auto issue_w = [&](int step, int slot) {
-    const int tap = step % 9, chunk = step / 9;
+    const int tap = step % NT, chunk = step / NT;
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       const int blk = i * 4 + wave;
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(ConvArgs a, int til
       for (int q = tid; q < IH * IW * 8; q += 256) {
         const int pos = q >> 3, part = q & 7;
         const int py = pos / IW, px = pos - py * IW;
-        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const int iy = oy0 - PAD + py, ix = ox0 - PAD + px;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
           v = load_in_piece<unsigned short, true>(a, b, iy, ix, chunk * 64 + part * 8);
@@ -338,9 +349,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(ConvArgs a, int til
         if (q < IH * IW * 8) {
           const int pos = q >> 3, part = q & 7;
           const int py = pos / IW, px = pos - py * IW;
-          const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+          int iy = oy0 - PAD + py, ix = ox0 - PAD + px, cc = chunk;
+          if (MODE == 2) {  // (iy, ix) are phase-plane coordinates; chunk -> (phase, channel block)
+            const int nblk = a.Cx >> 6;
+            const int ph = chunk / nblk;
+            cc = chunk - ph * nblk;
+            iy = 2 * iy + (ph >> 1);
+            ix = 2 * ix + (ph & 1);
+          }
           if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
-            v = load_in_piece<unsigned short, false>(a, b, iy, ix, chunk * 64 + part * 8);
+            v = load_in_piece<unsigned short, false>(a, b, iy, ix, cc * 64 + part * 8);
           if (to_lds) *reinterpret_cast<uint4*>(in_tile + py * IROWB + px * POSB + part * 16) = v;
         }
         if (!to_lds) ireg[i] = v;
@@ -377,40 +395,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(ConvArgs a, int til
   wait_vmcnt<0>();
   lds_barrier();
 
-  // Main loop.  9 taps fully unrolled, so ring slots (step % 3 == tap % 3) and the
-  // fragment double buffer (k-step parity) are static.  Rolling prefetch: while the 4
-  // MFMAs of one k-step run, the 2 A + 2 B fragments of the NEXT k-step are already
-  // in flight (32 fragment VGPRs in total), and one DMA block of the slab two steps
-  // ahead is issued per k-step, so LDS latency and DMA issue hide behind MFMAs.
+  // Main loop.  The NT taps of a chunk are fully unrolled (static patch offsets and
+  // fragment double buffer); the ring slot advances at run time.  Rolling prefetch:
+  // while the 4 MFMAs of one k-step run, the 2 A + 2 B fragments of the NEXT k-step
+  // are already in flight (32 fragment VGPRs in total), and one DMA block of the slab
+  // two steps ahead is issued per k-step, so LDS latency and DMA issue hide behind
+  // MFMAs.
+  constexpr int PF_TAP = NT >= 5 ? NT - 4 : 0;  // where the next patch's loads are issued
   bf16x8 fa[2][2], fb[2][2];  // [k-step parity][tile]
   auto read_a = [&](int buf, int tap, int s4) {
-    const int toff = (tap / 3) * IROWB + (tap % 3) * POSB + s4 * 16;
+    const int toff = (tap / KW) * IROWB + (tap % KW) * POSB + s4 * 16;
     fa[buf][0] = *reinterpret_cast<const bf16x8*>(in_tile + aoff[0] + toff);
     fa[buf][1] = *reinterpret_cast<const bf16x8*>(in_tile + aoff[1] + toff);
   };
-  auto read_b = [&](int buf, int tap, int s4) {
-    const unsigned char* wbuf = w_tile + (tap % 3) * W_BYTES;
+  auto read_b = [&](int buf, int slot, int s4) {
+    const unsigned char* wbuf = w_tile + slot * W_BYTES;
     fb[buf][0] = *reinterpret_cast<const bf16x8*>(wbuf + boff[0][s4]);
     fb[buf][1] = *reinterpret_cast<const bf16x8*>(wbuf + boff[1][s4]);
   };
+  int slot = 0;  // ring slot of the current step's slab
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const bool last_chunk = chunk + 1 == nchunks;
     read_a(0, 0, 0);
-    read_b(0, 0, 0);
+    read_b(0, slot, 0);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      // slab two steps ahead: tap+2 of this chunk, or tap+2-9 of the next one
-      const int t2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;
-      const int c2 = tap + 2 < 9 ? chunk : chunk + 1;
+    for (int tap = 0; tap < NT; ++tap) {
+      // slab two steps ahead: tap+2 of this chunk, or tap+2-NT of the next one
+      const int t2 = tap + 2 < NT ? tap + 2 : tap + 2 - NT;
+      const int c2 = tap + 2 < NT ? chunk : chunk + 1;
       const bool more = c2 < nchunks;
-      const bool prefetch = !FUSED && tap == 5 && !last_chunk;
+      const bool prefetch = !FUSED && tap == PF_TAP && !last_chunk;
+      const int slot2 = slot >= 1 ? slot - 1 : 2;  // (slot + 2) % 3
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const int cur = s4 & 1, nxt = cur ^ 1;
         if (s4 < 3) {
           read_a(nxt, tap, s4 + 1);
-          read_b(nxt, tap, s4 + 1);
-        } else if (tap < 8) {
+          read_b(nxt, slot, s4 + 1);
+        } else if (tap < NT - 1) {
           read_a(nxt, tap + 1, 0);  // next tap's weights are only readable after the barrier
         }
         // keep the prefetch reads AHEAD of this k-step's MFMAs (hipcc's scheduler would
@@ -420,10 +442,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(ConvArgs a, int til
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
-        if (more && s4 < WPT) issue_w1(t2, c2, (tap + 2) % 3, s4);
+        if (more && s4 < WPT) issue_w1(t2, c2, slot2, s4);
       }
       if (prefetch) gather_in(chunk + 1, false);  // next patch -> registers
-      if (tap == 8 && !last_chunk) {
+      if (tap == NT - 1 && !last_chunk) {
         lds_barrier();  // every wave is done with this chunk's patch
         if (FUSED) gather_in(chunk + 1, true);
         else store_in();
@@ -434,7 +456,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(ConvArgs a, int til
       else if (more) wait_vmcnt<WPT>();
       else wait_vmcnt<0>();
       lds_barrier();
-      if (tap < 8) read_b(0, tap + 1, 0);
+      slot = slot == 2 ? 0 : slot + 1;
+      if (tap < NT - 1) read_b(0, slot, 0);
     }
   }
 
@@ -443,8 +466,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(ConvArgs a, int til
   // Instead: scale/shift in registers -> fp32 tile in LDS (the ring + patch area is
   // free now) -> every thread picks up 8 consecutive channels of a pixel, adds the
   // residual (one 16-B load), ReLU, rounds to bf16 once, and stores 16 B.
-  constexpr int OLD = BN + 4;  // fp32 row stride of the staged tile (16-B aligned rows)
-  static_assert(TH * 16 * OLD * 4 <= 3 * W_BYTES + IN_BYTES, "output tile must fit in LDS");
   float* otile = reinterpret_cast<float*>(smem);
   // (the loop's final lds_barrier already guarantees every wave is done reading LDS)
 #pragma unroll
@@ -539,7 +560,52 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Cout, int C
   }
 }
 
+// OIHW fp32 (k x k, stride 2, pad p) -> [tap'][co][phase*Cin + ci] bf16 of the
+// equivalent stride-1 conv over the 4 parity phases: input row 2*oy + ky - p =
+// 2*(oy + ty) + py with py = (ky - p) & 1, ty = (ky - p - py) / 2.
+__global__ void pack_weights_s2d_kernel(const float* __restrict__ w, int Cout, int Cin, int K, int pad,
+                                        int KT, int tmin, unsigned short* __restrict__ out) {
+  const size_t n = (size_t)KT * KT * Cout * 4 * Cin;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int ci = e % Cin;
+    size_t t = e / Cin;
+    const int ph = t % 4; t /= 4;
+    const int co = t % Cout; t /= Cout;
+    const int tx = t % KT, ty = t / KT;
+    const int ky = 2 * (ty + tmin) + (ph >> 1) + pad, kx = 2 * (tx + tmin) + (ph & 1) + pad;
+    float v = 0.f;
+    if (ky >= 0 && ky < K && kx >= 0 && kx < K) v = w[(((size_t)co * Cin + ci) * K + ky) * K + kx];
+    out[e] = lss_f2bf(v);
+  }
+}
+
+// floor((0 - p) / 2) .. floor((k - 1 - p) / 2): tap range of the phase-plane conv
+inline int s2d_tmin(int pad) { return -((pad + 1) / 2); }
+inline int s2d_taps(int K, int pad) {
+  const int hi = (K - 1 - pad) >= 0 ? (K - 1 - pad) / 2 : -((pad - K + 2) / 2);
+  return hi - s2d_tmin(pad) + 1;
+}
+
 }  // namespace
+
+extern "C" size_t lss_conv2d_s2d_packed_weight_bytes(int Cout, int Cin, int K, int pad) {
+  if (Cout <= 0 || Cin <= 0 || K <= 0 || pad < 0) return 0;
+  const int kt = s2d_taps(K, pad);
+  return (size_t)kt * kt * Cout * 4 * Cin * 2;
+}
+
+extern "C" int lss_conv2d_pack_weights_s2d(const float* w_oihw, int Cout, int Cin, int K, int pad,
+                                           void* w_packed, void* stream) {
+  LSS_CHECK_PTR(w_oihw); LSS_CHECK_PTR(w_packed);
+  LSS_CHECK_POS(Cout); LSS_CHECK_POS(Cin); LSS_CHECK_POS(K);
+  if (pad < 0) return LSS_E_SHAPE;
+  const int kt = s2d_taps(K, pad);
+  const size_t n = (size_t)kt * kt * Cout * 4 * Cin;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(pack_weights_s2d_kernel, dim3(grid), dim3(256), 0, lss_stream(stream), w_oihw, Cout,
+                     Cin, K, pad, kt, s2d_tmin(pad), reinterpret_cast<unsigned short*>(w_packed));
+  return lss_launch_status();
+}
 
 extern "C" size_t lss_conv2d_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int dt) {
   if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
@@ -603,13 +669,13 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
     if (Cout <= 64) {
       const int tilesY = lss_cdiv(a.Ho, 16);
       dim3 g(tilesX * tilesY * B, lss_cdiv(Cout, 64));
-      if (fused) hipLaunchKernelGGL((conv3x3_lds_kernel<16, 64, true>), g, dim3(256), 0, st, a, tilesX, tilesY);
-      else hipLaunchKernelGGL((conv3x3_lds_kernel<16, 64, false>), g, dim3(256), 0, st, a, tilesX, tilesY);
+      if (fused) hipLaunchKernelGGL((conv_lds_kernel<16, 64, 1, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
+      else hipLaunchKernelGGL((conv_lds_kernel<16, 64, 0, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
     } else {
       const int tilesY = lss_cdiv(a.Ho, 8);
       dim3 g(tilesX * tilesY * B, lss_cdiv(Cout, 128));
-      if (fused) hipLaunchKernelGGL((conv3x3_lds_kernel<8, 128, true>), g, dim3(256), 0, st, a, tilesX, tilesY);
-      else hipLaunchKernelGGL((conv3x3_lds_kernel<8, 128, false>), g, dim3(256), 0, st, a, tilesX, tilesY);
+      if (fused) hipLaunchKernelGGL((conv_lds_kernel<8, 128, 1, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
+      else hipLaunchKernelGGL((conv_lds_kernel<8, 128, 0, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
     }
     return lss_launch_status();
   }
@@ -619,6 +685,46 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   } else {
     if (fused) hipLaunchKernelGGL((conv_direct_kernel<float, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_direct_kernel<float, false>), grid, dim3(256), 0, st, a);
+  }
+  return lss_launch_status();
+}
+
+// Stride-2 k x k conv (k = 3 pad 1, or k = 7 pad 3) on the LDS-tiled kernel through
+// the phase-plane (space-to-depth) form; `w_s2d` from lss_conv2d_pack_weights_s2d.
+extern "C" int lss_conv2d_s2_fwd(const void* x, const void* w_s2d, const float* scale,
+                                 const float* shift, const void* residual, void* y, float* stats,
+                                 int B, int H, int W, int Cx, int Cout, int K, int pad, int relu,
+                                 void* stream) {
+  LSS_CHECK_PTR(x); LSS_CHECK_PTR(w_s2d); LSS_CHECK_PTR(y);
+  LSS_CHECK_POS(B); LSS_CHECK_POS(H); LSS_CHECK_POS(W); LSS_CHECK_POS(Cx); LSS_CHECK_POS(Cout);
+  if (!((K == 3 && pad == 1) || (K == 7 && pad == 3))) return LSS_E_SHAPE;
+  if (Cx % 64 != 0) return LSS_E_SHAPE;
+  ConvArgs a;
+  a.x = x; a.x2 = nullptr; a.w = w_s2d; a.scale = scale; a.shift = shift; a.residual = residual;
+  a.y = y; a.stats = stats;
+  a.B = B; a.H = H; a.W = W; a.Cx = Cx; a.C2 = 0; a.up = 1;
+  a.Hin = H; a.Win = W; a.Cin = 4 * Cx;
+  a.Cout = Cout; a.KH = K; a.KW = K; a.stride = 2; a.pad = pad;
+  a.Ho = (H + 2 * pad - K) / 2 + 1;
+  a.Wo = (W + 2 * pad - K) / 2 + 1;
+  if (a.Ho <= 0 || a.Wo <= 0) return LSS_E_SHAPE;
+  const long long M = (long long)B * a.Ho * a.Wo;
+  if (M >= (1LL << 31)) return LSS_E_SHAPE;
+  a.M = (int)M;
+  a.relu = relu;
+  a.ry = a.rx = 0.f;
+  hipStream_t st = lss_stream(stream);
+  const int tilesX = lss_cdiv(a.Wo, 16);
+  if (Cout <= 64) {
+    const int tilesY = lss_cdiv(a.Ho, 16);
+    dim3 g(tilesX * tilesY * B, lss_cdiv(Cout, 64));
+    if (K == 7) hipLaunchKernelGGL((conv_lds_kernel<16, 64, 2, 4, 4, 2>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    else hipLaunchKernelGGL((conv_lds_kernel<16, 64, 2, 2, 2, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
+  } else {
+    const int tilesY = lss_cdiv(a.Ho, 8);
+    dim3 g(tilesX * tilesY * B, lss_cdiv(Cout, 128));
+    if (K == 7) hipLaunchKernelGGL((conv_lds_kernel<8, 128, 2, 4, 4, 2>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    else hipLaunchKernelGGL((conv_lds_kernel<8, 128, 2, 2, 2, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
   }
   return lss_launch_status();
 }

@@ -56,12 +56,21 @@ class _FoldedConv:
             src += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
         return src
 
+    def _s2d(self, dt):
+        """Stride-2 3x3/pad1 and 7x7/pad3 convs run on the LDS-tiled kernel through the
+        phase-plane (space-to-depth) weight arrangement (bf16 path only)."""
+        c = self.conv
+        return (dt == ops.DT_BF16 and c.stride[0] == 2 and c.kernel_size in ((3, 3), (7, 7))
+                and c.padding[0] == c.kernel_size[0] // 2 and c.in_channels % 64 == 0)
+
     def get(self, dt):
         src = self._sources()
         key = (dt,) + tuple((t.data_ptr(), t._version) for t in src)
         if key != self.key:
             with torch.no_grad():
-                self.w = ops.pack_conv_weight(self.conv.weight.detach().float().contiguous(), dt)
+                w32 = self.conv.weight.detach().float().contiguous()
+                self.w = ops.pack_conv_weight_s2d(w32, self.conv.padding[0]) if self._s2d(dt) \
+                    else ops.pack_conv_weight(w32, dt)
                 if self.bn is not None:
                     inv = torch.rsqrt(self.bn.running_var.float() + self.bn.eps)
                     self.scale = (self.bn.weight.float() * inv).contiguous()
@@ -75,6 +84,8 @@ class _FoldedConv:
     def run(self, x, dt, relu, residual=None, x2=None, up=1):
         w, scale, shift = self.get(dt)
         c = self.conv
+        if self._s2d(dt) and x2 is None and up == 1:
+            return ops.conv2d_s2_nhwc(x, w, c.kernel_size[0], c.padding[0], scale, shift, residual, relu)
         return ops.conv2d_nhwc(x, w, c.kernel_size, c.stride[0], c.padding[0], scale, shift, residual, relu,
                                x2=x2, up=up, dt=dt)
 

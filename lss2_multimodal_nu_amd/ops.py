@@ -249,6 +249,42 @@ def conv2d_nhwc(x, w_packed, ksize, stride, pad, scale=None, shift=None, residua
     return y
 
 
+def pack_conv_weight_s2d(w_oihw, pad):
+    """OIHW fp32 of a stride-2 k x k conv -> bf16 [tap'][Cout][4*Cin] for conv2d_s2_nhwc."""
+    Cout, Cin, K, K2 = w_oihw.shape
+    _f32c(w_oihw, "conv weight")
+    nbytes = N.lib().lss_conv2d_s2d_packed_weight_bytes(Cout, Cin, K, pad)
+    taps = nbytes // (Cout * 4 * Cin * 2)
+    out = torch.empty(taps, Cout, 4 * Cin, dtype=torch.bfloat16, device=w_oihw.device)
+    N.check(N.lib().lss_conv2d_pack_weights_s2d(N.ptr(w_oihw), Cout, Cin, K, pad, N.ptr(out), N.stream()),
+            "lss_conv2d_pack_weights_s2d")
+    return out
+
+
+def conv2d_s2_nhwc(x, w_s2d, K, pad, scale=None, shift=None, residual=None, relu=False, stats=None,
+                   tag="conv2d_fwd"):
+    """Stride-2 K x K conv (3/pad 1 or 7/pad 3), bf16 NHWC, on the LDS-tiled kernel."""
+    B, H, W, Cx = x.shape
+    taps, Cout, C4 = w_s2d.shape
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or w_s2d.dtype != torch.bfloat16 or C4 != 4 * Cx:
+        raise ValueError("conv2d_s2_nhwc operands must be contiguous bf16 with s2d-packed weights")
+    Ho, Wo = (H + 2 * pad - K) // 2 + 1, (W + 2 * pad - K) // 2 + 1
+    y = torch.empty(B, Ho, Wo, Cout, dtype=torch.bfloat16, device=x.device)
+    for name, t in (("scale", scale), ("shift", shift)):
+        if t is not None:
+            _f32c(t, name, (Cout,))
+    if residual is not None and (residual.dtype != torch.bfloat16 or tuple(residual.shape) != tuple(y.shape)
+                                 or not residual.is_contiguous()):
+        raise ValueError("residual must match the output")
+    if stats is not None:
+        _f32c(stats, "stats", (2 * Cout,))
+    with _timed(tag):
+        N.check(N.lib().lss_conv2d_s2_fwd(N.ptr(x), N.ptr(w_s2d), N.ptr(scale), N.ptr(shift), N.ptr(residual),
+                                          N.ptr(y), N.ptr(stats), B, H, W, Cx, Cout, K, pad, 1 if relu else 0,
+                                          N.stream()), "lss_conv2d_s2_fwd")
+    return y
+
+
 def nchw_to_nhwc(x, dt):
     """(B,C,H,W) fp32 contiguous -> (B,H,W,C) in dt."""
     _f32c(x, "x")

@@ -317,6 +317,47 @@ def test_k8_conv_vs_torch(ops, cfg, dt):
     np.testing.assert_allclose(s[Cout:].numpy(), (raw ** 2).sum((0, 2, 3)).numpy(), rtol=max(tol * 4, 1e-4))
 
 
+S2_CONVS = [  # B, H, W, Cin, Cout, k, relu, residual
+    (2, 20, 24, 64, 64, 7, True, False),
+    (1, 21, 19, 64, 128, 3, True, False),
+    (2, 50, 50, 128, 256, 3, False, True),
+    (1, 33, 40, 64, 64, 3, True, False),
+    (1, 37, 18, 128, 200, 7, False, False),
+]
+
+
+@pytest.mark.parametrize("cfg", S2_CONVS)
+def test_k8_stride2_conv_phase_plane_path(ops, cfg):
+    """Stride-2 convs through the space-to-depth form of the LDS-tiled kernel."""
+    B, H, W, Cin, Cout, k, relu, use_res = cfg
+    pad = k // 2
+    gen = torch.Generator().manual_seed(sum(cfg[:6]))
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) * (Cin * k * k) ** -0.5
+    scale = torch.rand(Cout, generator=gen) + 0.5
+    shift = torch.randn(Cout, generator=gen) * 0.1
+    raw = torch.nn.functional.conv2d(x, w, None, stride=2, padding=pad)
+    ref = raw * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    res = torch.randn(ref.shape, generator=gen) if use_res else None
+    if use_res:
+        ref = ref + res
+    if relu:
+        ref = ref.relu()
+    xg = ops.nchw_to_nhwc(x.cuda(), 1)
+    resg = ops.nchw_to_nhwc(res.cuda(), 1) if use_res else None
+    wp = ops.pack_conv_weight_s2d(w.cuda(), pad)
+    stats = torch.zeros(2 * Cout, device="cuda")
+    y = ops.conv2d_s2_nhwc(xg, wp, k, pad, scale.cuda(), shift.cuda(), resg, relu, stats)
+    out = ops.nhwc_to_nchw(y, 1).cpu()
+    assert out.shape == ref.shape
+    assert float((out - ref).abs().max()) <= 2.5e-2 * float(ref.abs().max()) + 1e-6
+    # and it agrees with the generic direct kernel on the same bf16 inputs to fp32-sum noise
+    y0 = ops.conv2d_nhwc(xg, ops.pack_conv_weight(w.cuda(), 1), (k, k), 2, pad, scale.cuda(), shift.cuda(), resg, relu, dt=1)
+    assert float((y.float() - y0.float()).abs().max()) <= 1.6e-2 * float(ref.abs().max())
+    np.testing.assert_allclose(stats[:Cout].cpu().numpy(), raw.sum((0, 2, 3)).numpy(), rtol=0.1,
+                               atol=0.1 * float(raw.abs().sum((0, 2, 3)).max()))
+
+
 def test_bad_arguments_raise(ops):
     ws = ops.SplatWorkspace(10, 10, "cuda")
     with pytest.raises(ValueError):

@@ -55,12 +55,17 @@ def main():
         for name, H, W, Cx, Cout, k, st, pad, C2, up, res in CONVS:
             x = torch.randn(B, H, W, Cx, device="cuda").to(torch.bfloat16)
             x2 = torch.randn(B, H * up, W * up, C2, device="cuda").to(torch.bfloat16) if C2 else None
-            w = ops.pack_conv_weight(torch.randn(Cout, Cx + C2, k, k, device="cuda") * 0.05, dt)
+            s2 = st == 2 and k in (3, 7)
+            wraw = torch.randn(Cout, Cx + C2, k, k, device="cuda") * 0.05
+            w = ops.pack_conv_weight_s2d(wraw, pad) if s2 else ops.pack_conv_weight(wraw, dt)
             sc, sh = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda")
             Ho = (H * up + 2 * pad - k) // st + 1
             Wo = (W * up + 2 * pad - k) // st + 1
             r = torch.randn(B, Ho, Wo, Cout, device="cuda").to(torch.bfloat16) if res else None
-            us = timeit(lambda: ops.conv2d_nhwc(x, w, (k, k), st, pad, sc, sh, r, True, x2, up, None, dt), args.iters)
+            if s2:
+                us = timeit(lambda: ops.conv2d_s2_nhwc(x, w, k, pad, sc, sh, r, True), args.iters)
+            else:
+                us = timeit(lambda: ops.conv2d_nhwc(x, w, (k, k), st, pad, sc, sh, r, True, x2, up, None, dt), args.iters)
             fl = 2.0 * B * Ho * Wo * Cout * (Cx + C2) * k * k
             n = COUNT.get(name, 1)
             tot_us += us * n
