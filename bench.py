@@ -58,6 +58,24 @@ def l1_bytes_per_frame(N, fH, fW, C, X, Y, Z, D, out_bytes):
     return N * 512 * fH * fW * 4 + C * Z * X * Y * out_bytes
 
 
+def pmc_traffic(kernel_prefix, grid=None):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json,
+    made by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes of this same
+    command); None when no such file exists.  bench.py itself cannot run the profiler."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    tot, n = 0.0, 0
+    for k, v in d.items():
+        name, g = k.split("|")
+        if name.startswith(kernel_prefix) and (grid is None or g == str(grid)):
+            tot += (v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
+            n += v["launches"]
+    return {"bytes_per_launch": tot / n, "source": os.path.basename(files[-1])} if n else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,12 +184,13 @@ def main():
                                "features are the input" % B,
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d (sample-sharded, no collective)" % world,
                    "precision": args.precision, "calibration": "CPU tensors per step; 3x3 inverses on host (exact-index contract), 1.7 KB H2D"},
-        "roofline": {"kernel": "conv_direct_kernel (19 BevEncode conv launches/step)", "bound": "mfma",
-                     "achieved": conv_tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": conv_tf / peak_tf,
-                     "traffic": None, "launches": n_conv, "avg_us": ms_conv * 1e3 / max(n_conv, 1),
-                     "flops_per_step": conv_flops_step},
+        "roofline": {"kernel": "conv_lds_kernel + conv_direct_kernel (the 19 BevEncode conv launches of a step)",
+                     "bound": "mfma", "achieved": conv_tf, "peak": peak_tf, "unit": "TFLOP/s",
+                     "frac": conv_tf / peak_tf, "traffic": pmc_traffic("conv_"), "launches": n_conv,
+                     "avg_us": ms_conv * 1e3 / max(n_conv, 1), "flops_per_step": conv_flops_step},
         "roofline_l1": {"kernel": "lift_splat_fwd_kernel", "bound": "hbm", "achieved": spl_gbs, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": spl_gbs / HBM_PEAK_GBS, "traffic": None, "launches": n_spl,
+                        "unit": "GB/s", "frac": spl_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("lift_splat_fwd_kernel"),
+                        "launches": n_spl,
                         "avg_us": ms_spl * 1e3 / max(n_spl, 1), "bytes_per_launch": splat_bytes_step},
         "levels": {"L2_hot_path_fps": fps,
                    "L1_lift_splat_fps": frames / dt_l1, "L1_ms_per_step": dt_l1 / args.steps * 1e3,
@@ -194,33 +213,28 @@ def main():
 
 
 def train_leg(args, model, feats, calib, dev, dist, world, B):
+    """fwd + bwd + one flat-bucket gradient all-reduce (RCCL) + clip + Adam: the
+    reference's train.py:49-66 loop body on synthetic tensors."""
     import lss2_multimodal_nu_amd as L
+    from lss2_multimodal_nu_amd import dp
     torch.manual_seed(0)
     m = L.compile_model_lss(B, GRID, AUG, 4, precision=args.precision).to(dev).train()
-    params = [p for p in m.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-8)  # ref: train.py:42
+    bucket = dp.GradBucket(m.parameters())
+    opt = torch.optim.Adam(bucket.params, lr=1e-4, weight_decay=1e-8)  # ref: train.py:42
     tgt = torch.randint(0, 4, (B, 200, 200), device=dev)
-    weight = torch.tensor([1.0, 10.0, 5.0, 10.0], device=dev)   # ref: src/tools.py:234
-    nparam = sum(p.numel() for p in params)
-    bucket = torch.zeros(nparam, device=dev)
+    weight = torch.tensor([1.0, 10.0, 5.0, 10.0], device=dev)         # ref: src/tools.py:234
+
+    def loss_fn(y):
+        return torch.nn.functional.cross_entropy(y, tgt, weight=weight)
 
     def one():
-        opt.zero_grad(set_to_none=True)
-        loss = torch.nn.functional.cross_entropy(m(feats, *calib), tgt, weight=weight)
-        loss.backward()
-        if dist is not None:  # one flat fp32 bucket, one RCCL all-reduce over xGMI
-            o = 0
-            for p in params:
-                bucket[o:o + p.numel()].copy_(p.grad.reshape(-1))
-                o += p.numel()
-            dist.all_reduce(bucket)
-            bucket.div_(world)
-            o = 0
-            for p in params:
-                p.grad.copy_(bucket[o:o + p.numel()].view_as(p.grad))
-                o += p.numel()
-        torch.nn.utils.clip_grad_norm_(params, 5.0)             # ref: train.py:64
-        opt.step()
+        if dist is not None:
+            dp.train_step(m, bucket, opt, loss_fn, (feats,) + tuple(calib))
+        else:
+            opt.zero_grad(set_to_none=True)
+            loss_fn(m(feats, *calib)).backward()
+            torch.nn.utils.clip_grad_norm_(bucket.params, 5.0)      # ref: train.py:64
+            opt.step()
 
     for _ in range(2):
         one()
@@ -238,7 +252,7 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt[0])
     return {"samples_per_s": args.train_steps * B * world / dt, "ms_per_step": dt / args.train_steps * 1e3,
-            "steps": args.train_steps, "grad_bucket_MB": nparam * 4 / 1e6,
+            "steps": args.train_steps, "grad_bucket_MB": bucket.numel * 4 / 1e6,
             "note": "lift-splat fwd/bwd native HIP; BevEncode fwd/bwd + BN batch stats via torch/MIOpen (not yet native)"}
 
 
