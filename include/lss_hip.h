@@ -195,6 +195,15 @@ int lss_conv2d_s2_fwd(const void* x, const void* w_s2d, const float* scale, cons
                       const void* residual, void* y, float* stats, int B, int H, int W, int Cx,
                       int Cout, int K, int pad, int relu, void* stream);
 
+/* 3x3/s1/p1 conv (+ fused upsample/concat gather) + scale/shift + ReLU + fused 1x1
+ * head, bf16 in, NCHW fp32 out (B, head_n, H*up, W*up).  Cout must be 128.
+ * replaces: src/modules.py:110-116 (up2: upsample, conv3x3, BN, ReLU, conv1x1+bias)
+ *   head_w (head_n, 128) fp32, head_b (head_n) fp32 */
+int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_packed, const float* scale,
+                        const float* shift, const float* head_w, const float* head_b, float* out,
+                        int B, int H, int W, int Cx, int C2, int up, int Cout, int head_n,
+                        int relu, void* stream);
+
 /* Layout / dtype conversion helpers between the reference's NCHW fp32 tensors
  * and the conv path's NHWC tensors. */
 int lss_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int dt,

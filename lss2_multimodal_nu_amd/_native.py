@@ -34,6 +34,7 @@ SIGNATURES = {
     "lss_conv2d_s2d_packed_weight_bytes": (_sz, [_i] * 4),
     "lss_conv2d_pack_weights_s2d": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "lss_conv2d_s2_fwd": (_i, [_vp] * 7 + [_i] * 8 + [_vp]),
+    "lss_conv2d_head_fwd": (_i, [_vp] * 8 + [_i] * 9 + [_vp]),
     "lss_nchw_f32_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "lss_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }

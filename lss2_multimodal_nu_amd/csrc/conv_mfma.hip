@@ -39,6 +39,12 @@ struct ConvArgs {
   int Ho, Wo, M;
   int relu;
   float ry, rx;  // (H-1)/(Hin-1), (W-1)/(Win-1) for the align_corners upsample
+  // optional fused 1x1 head (ref: src/modules.py:115 up2[4]): out[b,k,oy,ox] =
+  // head_b[k] + sum_co act(...)[co] * head_w[k, co]; NCHW fp32; needs Cout == BN
+  const float* head_w;
+  const float* head_b;
+  float* head_out;
+  int head_n;
 };
 
 template <typename T>
@@ -263,8 +269,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // (space-to-depth done by the gather: chunk -> (phase, 64-channel block); weights
 // come pre-arranged as [tap'][co][phase*Cx + c] from lss_conv2d_pack_weights_s2d).
 // KH x KW = taps of the stride-1 problem, PAD = patch rows/cols before the output pixel.
-template <int TH, int BN, int MODE, int KH, int KW, int PAD>
+// RT = 32-pixel MFMA row tiles per wave (2: 4 image rows x 64 channels per wave, the
+// throughput shape; 1: 2 image rows, half the work per workgroup - used when the RT = 2
+// grid would leave CUs idle, where the per-workgroup critical path is what counts).
+template <int RT, int BN, int MODE, int KH, int KW, int PAD>
 __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX, int tilesY) {
+  constexpr int TH = (4 / (BN / 64)) * RT * 2;  // image rows per workgroup
   constexpr bool FUSED = MODE == 1;
   constexpr int NT = KH * KW;
   constexpr int TW = 16, IW = TW + KW - 1, IH = TH + KH - 1, POSB = 144;
@@ -291,19 +301,20 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
   const int b = t / tilesY;
   const int oy0 = ty * TH, ox0 = tx * TW, n0 = blockIdx.y * BN;
   const int wc = wave % WCOLS, wr = wave / WCOLS;
-  const int prow0 = wr * 4;
+  const int prow0 = wr * (2 * RT);
 
-  int aoff[2], boff[2][4];
+  int aoff[RT], boff[2][4];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) aoff[i] = (prow0 + 2 * i + (r >> 4)) * IROWB + (r & 15) * POSB + h * 64;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    aoff[i] = (prow0 + 2 * i + (r >> 4)) * IROWB + (r & 15) * POSB + h * 64;
     const int row = wc * 64 + i * 32 + r;
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) boff[i][s4] = row * 128 + (((4 * h + s4) ^ ((row >> 1) & 7)) << 4);
   }
-  f32x16 acc[2][2];
+  f32x16 acc[RT][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -402,11 +413,11 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
   // two steps ahead is issued per k-step, so LDS latency and DMA issue hide behind
   // MFMAs.
   constexpr int PF_TAP = NT >= 5 ? NT - 4 : 0;  // where the next patch's loads are issued
-  bf16x8 fa[2][2], fb[2][2];  // [k-step parity][tile]
+  bf16x8 fa[2][RT], fb[2][2];  // [k-step parity][tile]
   auto read_a = [&](int buf, int tap, int s4) {
     const int toff = (tap / KW) * IROWB + (tap % KW) * POSB + s4 * 16;
-    fa[buf][0] = *reinterpret_cast<const bf16x8*>(in_tile + aoff[0] + toff);
-    fa[buf][1] = *reinterpret_cast<const bf16x8*>(in_tile + aoff[1] + toff);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) fa[buf][i] = *reinterpret_cast<const bf16x8*>(in_tile + aoff[i] + toff);
   };
   auto read_b = [&](int buf, int slot, int s4) {
     const unsigned char* wbuf = w_tile + slot * W_BYTES;
@@ -438,10 +449,11 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
         // keep the prefetch reads AHEAD of this k-step's MFMAs (hipcc's scheduler would
         // otherwise sink them next to their use and expose the LDS latency again)
         __builtin_amdgcn_sched_barrier(0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][0], acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][1], acc[i][1], 0, 0, 0);
+        }
         if (more && s4 < WPT) issue_w1(t2, c2, slot2, s4);
       }
       if (prefetch) gather_in(chunk + 1, false);  // next patch -> registers
@@ -477,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
     const float sh = (cok && a.shift) ? a.shift[co] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -503,6 +515,34 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
     }
   }
   lds_barrier();
+  if (a.head_out) {
+    // fused 1x1 head: the 16 lanes that hold the BN = 128 channels of one pixel reduce
+    // their partial dot products with shuffles; the activation itself is never stored
+    if (BN == 128) {
+      for (int e = tid; e < TH * 16 * 16; e += 256) {
+        const int pl = e >> 4, c8 = e & 15;
+        const int oy = oy0 + (pl >> 4), ox = ox0 + (pl & 15);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8 + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (a.relu) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        for (int k = 0; k < a.head_n; ++k) {
+          const float* hw = a.head_w + k * BN + c8 * 8;
+          float part = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) part = fmaf(v[j], hw[j], part);
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+          if (c8 == 0 && oy < a.Ho && ox < a.Wo)
+            a.head_out[(((size_t)b * a.head_n + k) * a.Ho + oy) * a.Wo + ox] = part + a.head_b[k];
+        }
+      }
+    }
+    return;
+  }
   unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
   const unsigned short* res = reinterpret_cast<const unsigned short*>(a.residual);
   const bool vec_ok = (a.Cout & 7) == 0;  // 16-B aligned channel groups
@@ -586,6 +626,30 @@ inline int s2d_taps(int K, int pad) {
   return hi - s2d_tmin(pad) + 1;
 }
 
+// Tile selection + launch of conv_lds_kernel.  BN = 64 for narrow layers, else 128; RT = 2
+// (throughput shape) unless that grid would leave the 256 CUs under-filled, in which case
+// half-height workgroups (RT = 1) shorten the per-workgroup critical path instead.
+template <int MODE, int KH, int KW, int PAD>
+void launch_conv_lds(const ConvArgs& a, hipStream_t st) {
+  const int tilesX = lss_cdiv(a.Wo, 16);
+  const bool narrow = a.Cout <= 64;
+  const int th2 = narrow ? 16 : 8;
+  const int nblk = lss_cdiv(a.Cout, narrow ? 64 : 128);
+  const long long nwg2 = (long long)tilesX * lss_cdiv(a.Ho, th2) * a.B * nblk;
+  int rt = nwg2 < 384 ? 1 : 2;
+  if (const char* e = getenv("LSS_CONV_RT")) rt = atoi(e) == 1 ? 1 : 2;
+  const int th = rt == 2 ? th2 : th2 / 2;
+  const int tilesY = lss_cdiv(a.Ho, th);
+  dim3 g(tilesX * tilesY * a.B, nblk);
+  if (narrow) {
+    if (rt == 2) hipLaunchKernelGGL((conv_lds_kernel<2, 64, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    else hipLaunchKernelGGL((conv_lds_kernel<1, 64, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);
+  } else {
+    if (rt == 2) hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    else hipLaunchKernelGGL((conv_lds_kernel<1, 128, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);
+  }
+}
+
 }  // namespace
 
 extern "C" size_t lss_conv2d_s2d_packed_weight_bytes(int Cout, int Cin, int K, int pad) {
@@ -657,6 +721,7 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   if (M >= (1LL << 31)) return LSS_E_SHAPE;
   a.M = (int)M;
   a.relu = relu;
+  a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0;
   a.ry = a.Hin > 1 ? (float)(H - 1) / (float)(a.Hin - 1) : 0.f;
   a.rx = a.Win > 1 ? (float)(W - 1) / (float)(a.Win - 1) : 0.f;
   const bool fused = (up > 1) || (C2 > 0);
@@ -665,18 +730,8 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   hipStream_t st = lss_stream(stream);
   if (dt == LSS_DT_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && a.Cin % 64 == 0 &&
       getenv("LSS_CONV_DIRECT") == nullptr) {
-    const int tilesX = lss_cdiv(a.Wo, 16);
-    if (Cout <= 64) {
-      const int tilesY = lss_cdiv(a.Ho, 16);
-      dim3 g(tilesX * tilesY * B, lss_cdiv(Cout, 64));
-      if (fused) hipLaunchKernelGGL((conv_lds_kernel<16, 64, 1, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
-      else hipLaunchKernelGGL((conv_lds_kernel<16, 64, 0, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
-    } else {
-      const int tilesY = lss_cdiv(a.Ho, 8);
-      dim3 g(tilesX * tilesY * B, lss_cdiv(Cout, 128));
-      if (fused) hipLaunchKernelGGL((conv_lds_kernel<8, 128, 1, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
-      else hipLaunchKernelGGL((conv_lds_kernel<8, 128, 0, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
-    }
+    if (fused) launch_conv_lds<1, 3, 3, 1>(a, st);
+    else launch_conv_lds<0, 3, 3, 1>(a, st);
     return lss_launch_status();
   }
   if (dt == LSS_DT_BF16) {
@@ -712,19 +767,47 @@ extern "C" int lss_conv2d_s2_fwd(const void* x, const void* w_s2d, const float* 
   if (M >= (1LL << 31)) return LSS_E_SHAPE;
   a.M = (int)M;
   a.relu = relu;
+  a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0;
   a.ry = a.rx = 0.f;
   hipStream_t st = lss_stream(stream);
-  const int tilesX = lss_cdiv(a.Wo, 16);
-  if (Cout <= 64) {
-    const int tilesY = lss_cdiv(a.Ho, 16);
-    dim3 g(tilesX * tilesY * B, lss_cdiv(Cout, 64));
-    if (K == 7) hipLaunchKernelGGL((conv_lds_kernel<16, 64, 2, 4, 4, 2>), g, dim3(256), 0, st, a, tilesX, tilesY);
-    else hipLaunchKernelGGL((conv_lds_kernel<16, 64, 2, 2, 2, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
-  } else {
-    const int tilesY = lss_cdiv(a.Ho, 8);
-    dim3 g(tilesX * tilesY * B, lss_cdiv(Cout, 128));
-    if (K == 7) hipLaunchKernelGGL((conv_lds_kernel<8, 128, 2, 4, 4, 2>), g, dim3(256), 0, st, a, tilesX, tilesY);
-    else hipLaunchKernelGGL((conv_lds_kernel<8, 128, 2, 2, 2, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
-  }
+  if (K == 7) launch_conv_lds<2, 4, 4, 2>(a, st);
+  else launch_conv_lds<2, 2, 2, 1>(a, st);
+  return lss_launch_status();
+}
+
+// 3x3 / stride 1 / pad 1 conv (optionally with the fused upsample / concat gather)
+// + scale/shift + ReLU + a fused 1x1 head, output NCHW fp32 (B, head_n, Ho, Wo).
+// BevEncode's last two layers (ref: src/modules.py:110-116, up2[0..4]) in one launch:
+// the 128-channel 200x200 activation and the NHWC->NCHW pass never touch HBM.
+extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_packed,
+                                   const float* scale, const float* shift, const float* head_w,
+                                   const float* head_b, float* out, int B, int H, int W, int Cx,
+                                   int C2, int up, int Cout, int head_n, int relu, void* stream) {
+  LSS_CHECK_PTR(x); LSS_CHECK_PTR(w_packed); LSS_CHECK_PTR(head_w); LSS_CHECK_PTR(head_b);
+  LSS_CHECK_PTR(out);
+  LSS_CHECK_POS(B); LSS_CHECK_POS(H); LSS_CHECK_POS(W); LSS_CHECK_POS(Cx); LSS_CHECK_POS(up);
+  LSS_CHECK_POS(head_n);
+  if (Cout != 128 || C2 < 0 || Cx % 64 != 0 || C2 % 64 != 0 || head_n > 64) return LSS_E_SHAPE;
+  if (C2 > 0 && x2 == nullptr) return LSS_E_NULL;
+  ConvArgs a;
+  a.x = x; a.x2 = x2; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = nullptr;
+  a.y = nullptr; a.stats = nullptr;
+  a.B = B; a.H = H; a.W = W; a.Cx = Cx; a.C2 = C2; a.up = up;
+  a.Hin = H * up; a.Win = W * up; a.Cin = Cx + C2;
+  a.Cout = Cout; a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1;
+  a.Ho = a.Hin; a.Wo = a.Win;
+  const long long M = (long long)B * a.Ho * a.Wo;
+  if (M >= (1LL << 31)) return LSS_E_SHAPE;
+  a.M = (int)M;
+  a.relu = relu;
+  a.head_w = head_w; a.head_b = head_b; a.head_out = out; a.head_n = head_n;
+  a.ry = a.Hin > 1 ? (float)(H - 1) / (float)(a.Hin - 1) : 0.f;
+  a.rx = a.Win > 1 ? (float)(W - 1) / (float)(a.Win - 1) : 0.f;
+  const bool fused = (up > 1) || (C2 > 0);
+  const int tilesX = lss_cdiv(a.Wo, 16), tilesY = lss_cdiv(a.Ho, 8);
+  dim3 g(tilesX * tilesY * B, 1);
+  hipStream_t st = lss_stream(stream);
+  if (fused) hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
+  else hipLaunchKernelGGL((conv_lds_kernel<2, 128, 0, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
   return lss_launch_status();
 }

@@ -233,8 +233,7 @@ class _LiftSplatMixin:
         dt = _PRECISIONS[be.precision or default_precision()]
         layout = ops.BEV_NHWC_BF16 if dt == ops.DT_BF16 else ops.BEV_NHWC_F32
         grid = self._lift_splat(x, rots, trans, intrins, post_rots, post_trans, layout)
-        y = be.forward_nhwc(grid.permute(0, 2, 3, 1), dt)
-        return ops.nhwc_to_nchw(y, dt)
+        return be.forward_nhwc(grid.permute(0, 2, 3, 1), dt)
 
 
 class LSS(_LiftSplatMixin, nn.Module):

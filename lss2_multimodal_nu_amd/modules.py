@@ -247,7 +247,7 @@ class BevEncode(nn.Module):
         return self.up2(x)
 
     def forward_nhwc(self, x, dt):
-        """HIP path on channels-last activations: x (B,X,Y,inC) in dt -> (B,X,Y,outC) in dt."""
+        """HIP path: x (B,X,Y,inC) channels-last activations in dt -> (B,outC,X,Y) fp32 NCHW."""
         x = self._stem.run(x, dt, relu=True)
         for blk in self.layer1:
             x = blk._nhwc(x, dt)
@@ -257,12 +257,18 @@ class BevEncode(nn.Module):
         for blk in self.layer3:
             x = blk._nhwc(x, dt)
         x = self.up1._nhwc(x, x1, dt)
+        if dt == ops.DT_BF16 and self.up2[1].out_channels == 128 and self.up2[4].out_channels <= 64:
+            # up2: x2 upsample + 3x3 conv + BN + ReLU + 1x1 head in ONE launch, NCHW fp32 out
+            w, scale, shift = self._up2a.get(dt)
+            head = self.up2[4]
+            hw = head.weight.detach().float().reshape(head.out_channels, -1).contiguous()
+            return ops.conv3x3_head_nchw(x, w, scale, shift, hw, head.bias.detach().float().contiguous(), up=2)
         x = self._up2a.run(x, dt, relu=True, up=2)
-        return self._up2b.run(x, dt, relu=False)
+        return ops.nhwc_to_nchw(self._up2b.run(x, dt, relu=False), dt)
 
     def forward(self, x):
+        """(B, inC, X, Y) -> (B, outC, X, Y) fp32 NCHW, like the reference."""
         if _needs_autograd(self, x):
             return self._forward_autograd(x.float() if x.dtype != torch.float32 else x)
         dt = _PRECISIONS[self.precision or default_precision()]
-        y = self.forward_nhwc(_to_nhwc(x, dt), dt)
-        return ops.nhwc_to_nchw(y, dt)
+        return self.forward_nhwc(_to_nhwc(x, dt), dt)

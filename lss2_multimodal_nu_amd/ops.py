@@ -285,6 +285,27 @@ def conv2d_s2_nhwc(x, w_s2d, K, pad, scale=None, shift=None, residual=None, relu
     return y
 
 
+def conv3x3_head_nchw(x, w_packed, scale, shift, head_w, head_b, x2=None, up=1, relu=True, tag="conv2d_fwd"):
+    """3x3/s1/p1 conv (+fused upsample/concat) + scale/shift + ReLU + 1x1 head in one launch.
+    x (B,H,W,Cx) bf16 NHWC; head_w (n,128) fp32; returns (B, n, H*up, W*up) fp32 NCHW."""
+    B, H, W, Cx = x.shape
+    taps, Cout, Cin = w_packed.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or taps != 9 or Cin != Cx + C2 or Cout != 128:
+        raise ValueError("conv3x3_head_nchw: bf16 NHWC input, 3x3 weights with Cout == 128 required")
+    n = head_w.shape[0]
+    _f32c(head_w, "head_w", (n, Cout))
+    _f32c(head_b, "head_b", (n,))
+    _f32c(scale, "scale", (Cout,))
+    _f32c(shift, "shift", (Cout,))
+    out = torch.empty(B, n, H * up, W * up, dtype=torch.float32, device=x.device)
+    with _timed(tag):
+        N.check(N.lib().lss_conv2d_head_fwd(N.ptr(x), N.ptr(x2), N.ptr(w_packed), N.ptr(scale), N.ptr(shift),
+                                            N.ptr(head_w), N.ptr(head_b), N.ptr(out), B, H, W, Cx, C2, up, Cout, n,
+                                            1 if relu else 0, N.stream()), "lss_conv2d_head_fwd")
+    return out
+
+
 def nchw_to_nhwc(x, dt):
     """(B,C,H,W) fp32 contiguous -> (B,H,W,C) in dt."""
     _f32c(x, "x")

@@ -358,6 +358,42 @@ def test_k8_stride2_conv_phase_plane_path(ops, cfg):
                                atol=0.1 * float(raw.abs().sum((0, 2, 3)).max()))
 
 
+@pytest.mark.parametrize("cfg", [(2, 12, 10, 256, 0, 2, 4), (1, 9, 16, 64, 0, 1, 3), (1, 5, 6, 128, 64, 4, 4)])
+def test_k8_conv_with_fused_head(ops, cfg):
+    """up2 of BevEncode in one launch: (upsample) + 3x3 conv + scale/shift + ReLU + 1x1 head -> NCHW fp32."""
+    B, H, W, Cx, C2, up, n = cfg
+    gen = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(B, Cx, H, W, generator=gen)
+    x2 = torch.randn(B, C2, H * up, W * up, generator=gen) if C2 else None
+    w = torch.randn(128, Cx + C2, 3, 3, generator=gen) * ((Cx + C2) * 9) ** -0.5
+    scale, shift = torch.rand(128, generator=gen) + 0.5, torch.randn(128, generator=gen) * 0.1
+    hw, hb = torch.randn(n, 128, generator=gen) * 128 ** -0.5, torch.randn(n, generator=gen)
+    xin = bo.upsample_bilinear_ac(x, up) if up > 1 else x
+    if C2:
+        xin = torch.cat([x2, xin], 1)
+    act = (torch.nn.functional.conv2d(xin, w, None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).relu()
+    ref = torch.nn.functional.conv2d(act, hw.view(n, 128, 1, 1), hb)
+    out = ops.conv3x3_head_nchw(ops.nchw_to_nhwc(x.cuda(), 1), ops.pack_conv_weight(w.cuda(), 1), scale.cuda(),
+                                shift.cuda(), hw.cuda(), hb.cuda(), x2=ops.nchw_to_nhwc(x2.cuda(), 1) if C2 else None,
+                                up=up).cpu()
+    assert out.shape == ref.shape and out.is_contiguous()
+    assert float((out - ref).abs().max()) <= 2.5e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("rt", ["1", "2"])
+def test_k8_conv_tile_variants_agree(ops, rt, monkeypatch):
+    """Both workgroup shapes (RT = 1 / 2 row tiles per wave) of the LDS-tiled kernel."""
+    monkeypatch.setenv("LSS_CONV_RT", rt)
+    gen = torch.Generator().manual_seed(11)
+    for (B, H, W, Cin, Cout) in ((2, 25, 25, 128, 256), (1, 37, 20, 64, 64), (1, 9, 50, 192, 130)):
+        x = torch.randn(B, Cin, H, W, generator=gen)
+        w = torch.randn(Cout, Cin, 3, 3, generator=gen) * (Cin * 9) ** -0.5
+        ref = torch.nn.functional.conv2d(x, w, None, padding=1)
+        y = ops.conv2d_nhwc(ops.nchw_to_nhwc(x.cuda(), 1), ops.pack_conv_weight(w.cuda(), 1), (3, 3), 1, 1, dt=1)
+        out = ops.nhwc_to_nchw(y, 1).cpu()
+        assert float((out - ref).abs().max()) <= 2.5e-2 * float(ref.abs().max())
+
+
 def test_bad_arguments_raise(ops):
     ws = ops.SplatWorkspace(10, 10, "cuda")
     with pytest.raises(ValueError):
