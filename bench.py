@@ -97,12 +97,19 @@ def main():
     # the box exposes 256 logical CPUs but grants ~16: keep torch's intra-op pool (used by the
     # per-step host calibration math) inside the grant
     torch.set_num_threads(host_cores())
+    # rehearsal hook for a 1-GPU box: LSS_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo
+    rehearse = os.environ.get("LSS_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import lss2_multimodal_nu_amd as L
     from lss2_multimodal_nu_amd import ops
