@@ -245,6 +245,67 @@ def test_k7_backward_vs_reference(ops, golden, name, channels_last):
     np.testing.assert_allclose(gx.numpy(), g["grad_feat_in"], rtol=1e-3, atol=1e-4 * np.abs(g["grad_feat_in"]).max())
 
 
+@pytest.mark.parametrize("cfg", [("c128_default", 2, 6, 41, 8, 22, 128, (200, 200, 1), False),
+                                 ("hires_c64", 2, 6, 60, 16, 44, 64, (400, 400, 1), True),
+                                 ("odd_grid_z3", 1, 3, 7, 5, 9, 64, (37, 53, 3), False)])
+def test_k5_k7_other_configs_vs_fp64(ops, cfg):
+    """C = 128 (VoVNet row of SURVEY 8a-10), the hi-res config 5 shapes, and a grid whose
+    X*Y is not a multiple of the 64-cell tile with Z > 1: forward vs the fp64 direct sum,
+    backward vs the fp64 adjoint."""
+    name, B, N, D, fH, fW, C, (X, Y, Z), hires = cfg
+    gen = torch.Generator().manual_seed(len(name))
+    if hires:
+        gc = GRID_HIRES
+        fr = lo.create_frustum((256, 704), 16, gc["dbound"])
+        dx, bx, nx = lo.gen_dx_bx(gc["xbound"], gc["ybound"], gc["zbound"])
+        rig = lo.synthetic_rig(B, final_dim=(256, 704), train_aug=True, seed=3)
+    else:
+        span = 50.0 if X == 200 else 12.0
+        dx, bx, nx = lo.gen_dx_bx([-span, span, 2 * span / X], [-span, span, 2 * span / Y], [-3.0, 3.0, 6.0 / Z])
+        fr = lo.create_frustum((fH * 16, fW * 16), 16, [4.0, 4.0 + D, 1.0])
+        rig = lo.synthetic_rig(B, N=N, final_dim=(fH * 16, fW * 16), train_aug=True, seed=2)
+        if X != 200:  # squeeze the rig into the small grid
+            rig = list(rig)
+            rig[2] = rig[2].clone()
+            rig[2][..., 0, 0] = 90.0; rig[2][..., 1, 1] = 90.0; rig[2][..., 0, 2] = fW * 8.0; rig[2][..., 1, 2] = fH * 8.0
+            rig[3] = torch.eye(3).repeat(B, N, 1, 1); rig[4] = torch.zeros(B, N, 3)
+    assert [int(v) for v in nx] == [X, Y, Z]
+    rots, trans, intr, prot, ptr = rig
+    inv_pr, comb = lo.calib_matrices(rots, intr, prot)
+    g = {"inv_post_rots": inv_pr.numpy(), "post_trans": ptr.numpy(), "combine": comb.numpy(), "trans": trans.numpy()}
+    ws, geom = run_k3(ops, g, fr, (dx, bx, nx))
+    geom_ref = lo.geometry_points_np(fr.numpy(), g["inv_post_rots"], g["post_trans"], g["combine"], g["trans"])
+    assert np.array_equal(geom.cpu().numpy(), geom_ref, equal_nan=True)
+    cell, iz = lo.cell_ids_np(geom_ref, dx.numpy(), bx.numpy(), nx.numpy())
+    vox_ref = np.where(cell >= 0, cell.astype(np.int64) * Z + iz, -1).astype(np.int32)
+    assert np.array_equal(ws.voxel.cpu().numpy(), vox_ref)
+    assert (vox_ref >= 0).mean() > 0.3
+    x = torch.randn(B * N, 512, fH, fW, generator=gen)
+    w = torch.randn(D + C, 512, 1, 1, generator=gen) * 512 ** -0.5
+    b = torch.randn(D + C, generator=gen) * 0.1
+    depth, feat = ops.depthnet_softmax(x.cuda(), w.cuda(), b.cuda(), D, C)
+    ops.bucket_points(ws, depth)
+    dims = (B, N, D, fH, fW, C)
+    outs = [ops.lift_splat_fwd(feat, ws, dims, (X, Y, Z), lay).float().cpu().numpy() for lay in (0, 1)]
+    assert np.array_equal(outs[0], outs[1])
+    direct = lo.splat_direct_np(cell, iz, depth.cpu().numpy(), feat.cpu().numpy().reshape(B * N, fH * fW, C).transpose(0, 2, 1),
+                                B, N, D, fH, fW, C, X, Y, Z)
+    np.testing.assert_allclose(outs[0], direct, rtol=3e-5, atol=3e-6 * np.abs(direct).max())
+    # backward: adjoint of the same linear map in fp64
+    G = torch.randn(B, Z * C, X, Y, generator=gen)
+    g_logits = ops.lift_splat_bwd(G.cuda().contiguous(memory_format=torch.channels_last), ws.voxel, depth, feat, dims, (X, Y, Z)).cpu()
+    Gr = G.double().view(B, Z, C, X, Y).permute(0, 3, 4, 1, 2).reshape(B * X * Y * Z, C).numpy()
+    rows = np.where(vox_ref[:, None] >= 0, Gr[np.clip(vox_ref, 0, None)], 0.0)          # (P, C)
+    dep = depth.cpu().double().numpy().reshape(B * N, D, fH * fW)
+    ft = feat.cpu().double().numpy().reshape(B * N, fH * fW, C)
+    rows = rows.reshape(B * N, D, fH * fW, C)
+    g_feat = np.einsum("bdp,bdpc->bpc", dep, rows)
+    g_dep = np.einsum("bpc,bdpc->bdp", ft, rows)
+    g_logit_d = dep * (g_dep - (dep * g_dep).sum(1, keepdims=True))
+    ref = np.concatenate([g_logit_d, g_feat.transpose(0, 2, 1)], 1).reshape(B * N, D + C, fH, fW)
+    np.testing.assert_allclose(g_logits.numpy(), ref, rtol=2e-4, atol=2e-5 * np.abs(ref).max())
+
+
 def test_segmented_sum(ops, golden):
     g = golden("g5_quickcumsum")
     ranks = g["ranks"]

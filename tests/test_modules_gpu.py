@@ -89,6 +89,30 @@ def test_lss_forward_vs_oracle(golden, precision, tol):
     assert float((out.cpu() - ref).abs().max()) < 5 * tol * float(ref.abs().max())
 
 
+def test_lss_forward_hires_config5_shapes():
+    """BASELINE config 5 shapes per GPU: 6 x (16x44) features, D = 60, 400 x 400 BEV, batch 2."""
+    grid = dict(xbound=[-50.0, 50.0, 0.25], ybound=[-50.0, 50.0, 0.25], zbound=[-10.0, 10.0, 20.0],
+                dbound=[1.0, 61.0, 1.0])
+    torch.manual_seed(5)
+    B = 2
+    m = L.compile_model_lss(B, grid, {"final_dim": (256, 704), "Ncams": 6}, 4, precision="bf16")
+    randomize_bn(m)
+    m = m.cuda().eval()
+    assert m.D == 60 and tuple(m.frustum.shape) == (60, 16, 44, 3)
+    calib = lo.synthetic_rig(B, final_dim=(256, 704), train_aug=True, seed=6)
+    x = torch.randn(B * 6, 512, 16, 44)
+    with torch.no_grad():
+        out = m(x.cuda(), *calib)
+        grid_t = m.get_voxels(x.cuda(), *calib)
+    assert out.shape == (B, 4, 400, 400) and grid_t.shape == (B, 64, 400, 400)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    ref_grid = lo.lift_splat_torch(x, sd["camencode.depthnet.weight"], sd["camencode.depthnet.bias"], sd["frustum"],
+                                   *calib, sd["dx"], sd["bx"], sd["nx"], B, 60, 64)
+    assert float((grid_t.cpu() - ref_grid).norm() / ref_grid.norm()) < 1e-3
+    ref = bo.bev_encode(ref_grid, {k[len("bevencode."):]: v for k, v in sd.items() if k.startswith("bevencode.")})
+    assert float((out.cpu() - ref).norm() / ref.norm()) < 4e-2
+
+
 def test_bevencode_and_up_modules_vs_oracle(golden):
     torch.manual_seed(2)
     be = L.BevEncode(64, 4, precision="fp32")
