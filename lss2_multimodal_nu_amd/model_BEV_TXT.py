@@ -219,7 +219,8 @@ class _LiftSplatMixin:
                                       self._nx_ints(), _PRECISIONS[ce.math], layout)
         depth, feat = ce.depth_and_context(x)
         ops.bucket_points(ws, depth)
-        return ops.lift_splat_fwd(feat, ws, dims, self._nx_ints(), layout)
+        with ops.region("lift_splat_fwd"):
+            return ops.lift_splat_fwd(feat, ws, dims, self._nx_ints(), layout, tag=None)
 
     def get_voxels(self, x, rots, trans, intrins, post_rots, post_trans):
         return self._lift_splat(x, rots, trans, intrins, post_rots, post_trans, ops.BEV_NCHW_F32)

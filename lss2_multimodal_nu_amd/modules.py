@@ -248,6 +248,10 @@ class BevEncode(nn.Module):
 
     def forward_nhwc(self, x, dt):
         """HIP path: x (B,X,Y,inC) channels-last activations in dt -> (B,outC,X,Y) fp32 NCHW."""
+        with ops.region("bevencode"):
+            return self._forward_nhwc(x, dt)
+
+    def _forward_nhwc(self, x, dt):
         x = self._stem.run(x, dt, relu=True)
         for blk in self.layer1:
             x = blk._nhwc(x, dt)

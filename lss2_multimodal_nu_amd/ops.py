@@ -24,8 +24,11 @@ class KernelTimer:
     the roofline numbers).  Events are recorded on torch's current stream - the
     stream the kernels are enqueued on."""
 
-    def __init__(self):
+    def __init__(self, fine=False):
+        # fine=True brackets every native launch (each bracket costs ~5-10 us of GPU idle
+        # time: diagnostics only); fine=False only the regions opened with `region()`
         self.spans = {}
+        self.fine = fine
 
     def bracket(self, tag):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -46,8 +49,8 @@ def set_timer(t):
 
 
 class _timed:
-    def __init__(self, tag):
-        self.ev = _timer.bracket(tag) if (_timer is not None and tag) else None
+    def __init__(self, tag, coarse=False):
+        self.ev = _timer.bracket(tag) if (_timer is not None and tag and (coarse or _timer.fine)) else None
 
     def __enter__(self):
         if self.ev:
@@ -57,6 +60,11 @@ class _timed:
         if self.ev:
             self.ev[1].record()
         return False
+
+
+def region(tag):
+    """Coarse HIP-event bracket around a group of launches (e.g. all of BevEncode)."""
+    return _timed(tag, coarse=True)
 
 
 class SplatWorkspace:
