@@ -96,12 +96,15 @@ int lss_geom_to_voxels(const float* geom, const float* dx, const float* bx, int 
  *   vox_count (nvox) int32 in/out: per-voxel point counts on entry (from K3),
  *             all zero again on return (ready for the next call)
  *   vox_list  (nvox) int2 out: {start, len} of each voxel's slice of `entries`
- *   entries   (P) int2 out: {point id, depth weight bits} grouped by voxel; the
+ *   D, HW     depth bins and pixels per camera image (point p = (bn*D + d)*HW + pix);
+ *             D <= 128, P/D < 2^24
+ *   entries   (P) int2 out: {key, depth weight bits} grouped by voxel, key =
+ *             (feature row << 7) | depth bin with feature row = bn*HW + pix; the
  *             order inside one voxel's slice is unspecified (K5 orders each
- *             slice by point id before summing, so BEV sums are reproducible)
+ *             slice by key before summing, so BEV sums are reproducible)
  *   cursor    (1) int32 in/out scratch, zero on entry, zero again on return
  */
-int lss_bucket_points(const int32_t* voxel, const float* depth, int P, int nvox,
+int lss_bucket_points(const int32_t* voxel, const float* depth, int P, int D, int HW, int nvox,
                       int32_t* vox_count, int32_t* vox_list /* nvox*2 */,
                       int32_t* entries /* P*2 */, int32_t* cursor, void* stream);
 

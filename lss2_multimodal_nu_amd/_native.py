@@ -23,7 +23,7 @@ SIGNATURES = {
     "lss_error_string": (ctypes.c_char_p, [_i]),
     "lss_points_to_voxels": (_i, [_vp] * 7 + [_i] * 8 + [_vp, _vp, _vp, _vp]),
     "lss_geom_to_voxels": (_i, [_vp, _vp, _vp] + [_i] * 5 + [_vp, _vp, _vp]),
-    "lss_bucket_points": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "lss_bucket_points": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lss_depthnet_softmax_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "lss_lift_splat_fwd": (_i, [_vp] * 3 + [_i] * 9 + [_vp, _i, _vp]),
     "lss_lift_splat_bwd": (_i, [_vp, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp, _vp]),

@@ -146,6 +146,7 @@ __global__ __launch_bounds__(1024) void bucket_alloc_kernel(const int32_t* __res
 // write the list entry {point id, depth weight}: K5 then needs no dependent
 // depth load.
 __global__ __launch_bounds__(256) void bucket_fill_kernel(const int32_t* __restrict__ voxel, int P,
+                                                          int D, int HW,
                                                           const float* __restrict__ depth,
                                                           int32_t* __restrict__ vox_count,
                                                           const int32_t* __restrict__ vox_list,
@@ -158,7 +159,11 @@ __global__ __launch_bounds__(256) void bucket_fill_kernel(const int32_t* __restr
   if (v < 0) return;
   const float w = depth ? depth[p] : 1.0f;  // depth is (BN, D, HW): flat index == point id
   const int slot = atomicSub(vox_count + v, 1) - 1;
-  entries[vox_list[2 * v] + slot] = make_int2(p, __builtin_bit_cast(int, w));
+  // key = (feature row << 7) | depth bin: unique per point, gives K5 the row without a
+  // division and a fixed order to sum in.  p = (bn*D + d)*HW + pix, row = bn*HW + pix
+  const int bd = p / HW, pix = p - bd * HW;
+  const int bn = bd / D, d = bd - bn * D;
+  entries[vox_list[2 * v] + slot] = make_int2(((bn * HW + pix) << 7) | d, __builtin_bit_cast(int, w));
 }
 
 // API-compat segmented sum (QuickCumsum.forward): one wave per run, lane = channel.
@@ -215,17 +220,19 @@ extern "C" int lss_geom_to_voxels(const float* geom, const float* dx, const floa
   return lss_launch_status();
 }
 
-extern "C" int lss_bucket_points(const int32_t* voxel, const float* depth, int P, int nvox,
-                                 int32_t* vox_count, int32_t* vox_list, int32_t* entries,
+extern "C" int lss_bucket_points(const int32_t* voxel, const float* depth, int P, int D, int HW,
+                                 int nvox, int32_t* vox_count, int32_t* vox_list, int32_t* entries,
                                  int32_t* cursor, void* stream) {
   LSS_CHECK_PTR(voxel); LSS_CHECK_PTR(vox_count); LSS_CHECK_PTR(vox_list);
   LSS_CHECK_PTR(entries); LSS_CHECK_PTR(cursor);
-  LSS_CHECK_POS(P); LSS_CHECK_POS(nvox);
+  LSS_CHECK_POS(P); LSS_CHECK_POS(nvox); LSS_CHECK_POS(D); LSS_CHECK_POS(HW);
+  // key packing: depth bin in 7 bits, feature row in the 24 bits above
+  if (D > 128 || P % (D * HW) != 0 || (long long)(P / D) >= (1LL << 24)) return LSS_E_SHAPE;
   if ((reinterpret_cast<uintptr_t>(entries) & 7) != 0) return LSS_E_ALIGN;
   hipLaunchKernelGGL(bucket_alloc_kernel, dim3(lss_cdiv(nvox, 1024)), dim3(1024), 0,
                      lss_stream(stream), vox_count, nvox, vox_list, cursor);
   hipLaunchKernelGGL(bucket_fill_kernel, dim3(lss_cdiv(P, 256)), dim3(256), 0,
-                     lss_stream(stream), voxel, P, depth, vox_count, vox_list,
+                     lss_stream(stream), voxel, P, D, HW, depth, vox_count, vox_list,
                      reinterpret_cast<int2*>(entries), cursor);
   return lss_launch_status();
 }

@@ -10,7 +10,9 @@
 // chunk are ordered by point id inside each voxel (rank sort over ds_bpermute ->
 // the fp32 summation order is fixed, results are run-to-run reproducible), then
 // the sum loop broadcasts (row, weight) with v_readlane while the 256-B feature
-// row loads - 16 in flight per lane - are coalesced.  The 64 x C tile is staged in
+// row loads - 16 in flight per lane - are coalesced; voxel boundaries come from one
+// wave-wide ballot (a bit test per entry).  The entry key is (feature row << 7) | depth
+// bin, so no integer division is needed here.  The 64 x C tile is staged in
 // LDS and written once, zeros for empty voxels included: no memset, no atomics,
 // every BEV byte stored exactly once, in 16-B-per-lane stores (NHWC) or 256-B
 // channel-plane segments (NCHW).
@@ -53,7 +55,7 @@ __device__ __forceinline__ void sum_voxel(const float* __restrict__ feat,
       dep = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dest, __builtin_bit_cast(int, dep)));
     }
     int row = 0;
-    if (lane < n) row = (pid / DHW) * HW + (pid % HW);
+    if (lane < n) row = pid >> 7;  // entry key = (feature row << 7) | depth bin
     for (int i = 0; i < n; ++i) {
       const int r = __builtin_amdgcn_readlane(row, i);
       const float dd = rl_f(dep, i);
@@ -165,7 +167,12 @@ __global__ __launch_bounds__(512) void lift_splat_fwd_kernel(
             dep = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dest, __builtin_bit_cast(int, dep)));
           }
           int row = 0;  // lanes >= n: row 0 with weight 0 -> harmless loads
-          if (lane < n) row = (pid / DHW) * HW + (pid % HW);
+          if (lane < n) row = pid >> 7;  // entry key = (feature row << 7) | depth bin
+          // bit i of lastmask: entry i closes its voxel's run -> the only per-entry scalar
+          // work left in the sum loop is one bit test
+          const int nslot = __shfl_down(slot, 1, 64);
+          const unsigned long long lastmask = __ballot(lane < n && (lane == n - 1 || nslot != slot));
+          for (int k = s; k < e; ++k) flush(k);  // zero rows; occupied voxels overwrite theirs below
           for (int i0 = 0; i0 < n; i0 += 16) {
             float f[16][CPL];
 #pragma unroll
@@ -178,14 +185,14 @@ __global__ __launch_bounds__(512) void lift_splat_fwd_kernel(
             for (int u = 0; u < 16; ++u) {
               const int i = i0 + u;
               if (i < n) {
-                const int sl = __builtin_amdgcn_readlane(slot, i);
-                while (cur < sl) flush(cur++);
                 const float dd = rl_f(dep, i);
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) acc[q] = fmaf(dd, f[u][q], acc[q]);
+                if ((lastmask >> i) & 1) flush(__builtin_amdgcn_readlane(slot, i));
               }
             }
           }
+          cur = e;
         }
         while (cur < e) flush(cur++);
         s = e;

@@ -121,14 +121,16 @@ def geom_to_voxels(geom, dx, bx, nx, B, ws, histogram=True):
             "lss_geom_to_voxels")
 
 
-def bucket_points(ws, depth=None):
+def bucket_points(ws, depth=None, D=1, HW=1):
     """K4 on a workspace whose voxel/vox_count were filled by K3.  `depth` = K2's
-    (BN,D,fH,fW) tensor (its flat index is the point id); None = unit weights."""
+    (BN,D,fH,fW) tensor (its flat index is the point id); None = unit weights with the
+    points taken as D = HW = 1 rows (pre-lifted inputs)."""
     if depth is not None:
         _f32c(depth, "depth")
-        if depth.numel() != ws.P:
-            raise ValueError("depth has %d elements, workspace has %d points" % (depth.numel(), ws.P))
-    N.check(N.lib().lss_bucket_points(N.ptr(ws.voxel), N.ptr(depth), ws.P, ws.nvox, N.ptr(ws.vox_count),
+        if depth.numel() != ws.P or depth.dim() != 4:
+            raise ValueError("depth must be (BN,D,fH,fW) with %d elements" % ws.P)
+        D, HW = depth.shape[1], depth.shape[2] * depth.shape[3]
+    N.check(N.lib().lss_bucket_points(N.ptr(ws.voxel), N.ptr(depth), ws.P, D, HW, ws.nvox, N.ptr(ws.vox_count),
                                       N.ptr(ws.vox_list), N.ptr(ws.entries), N.ptr(ws.cursor),
                                       N.stream()), "lss_bucket_points")
 
