@@ -79,6 +79,35 @@ __device__ __forceinline__ f32x4 lerp4(f32x4 a, f32x4 b, float t) {
   return r;
 }
 
+// bilinear blend of four 8-channel bf16 pieces in the four-weight form, on (lo, hi)
+// channel pairs: float2 arithmetic maps to v_pk_mul_f32 / v_pk_fma_f32.  One rounding to bf16.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 unpack_bf2(unsigned int u) {
+  f32x2 v;
+  v[0] = __builtin_bit_cast(float, u << 16);
+  v[1] = __builtin_bit_cast(float, u & 0xffff0000u);
+  return v;
+}
+__device__ __forceinline__ uint4 blend_bf16x8(const uint4& q00, const uint4& q01, const uint4& q10,
+                                              const uint4& q11, float lx, float ly) {
+  const float w11 = lx * ly, w10 = ly - w11, w01 = lx - w11, w00 = 1.f - lx - ly + w11;
+  const unsigned int* u00 = reinterpret_cast<const unsigned int*>(&q00);
+  const unsigned int* u01 = reinterpret_cast<const unsigned int*>(&q01);
+  const unsigned int* u10 = reinterpret_cast<const unsigned int*>(&q10);
+  const unsigned int* u11 = reinterpret_cast<const unsigned int*>(&q11);
+  uint4 out;
+  unsigned int* o = reinterpret_cast<unsigned int*>(&out);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x2 r = unpack_bf2(u00[i]) * w00;
+    r = __builtin_elementwise_fma(unpack_bf2(u01[i]), (f32x2){w01, w01}, r);
+    r = __builtin_elementwise_fma(unpack_bf2(u10[i]), (f32x2){w10, w10}, r);
+    r = __builtin_elementwise_fma(unpack_bf2(u11[i]), (f32x2){w11, w11}, r);
+    o[i] = lss_pack_bf2(r[0], r[1]);
+  }
+  return out;
+}
+
 // 16-B piece (bf16: 8 ch, f32: 4 ch) of pixel (b, iy, ix) of the conv's virtual
 // input, channel offset c (multiple of the piece size, never straddling x2 | x).
 template <typename T, bool FUSED>
@@ -295,7 +324,16 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  int t = blockIdx.x;
+  // XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin to
+  // the 8 XCDs, so give XCD k the k-th contiguous eighth of the tile list (= a band of image
+  // rows): neighbouring tiles then share halo rows through ONE L2 instead of every L2
+  // pulling the whole input from the Infinity Cache.  Bijective for any grid size.
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  }
   const int tx = t % tilesX; t /= tilesX;
   const int ty = t % tilesY;
   const int b = t / tilesY;
@@ -337,6 +375,70 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
              w_tile + slot * W_BYTES + blk * 1024);
     }
   };
+  // MODE 1: the bilinear source coordinates of a patch piece depend only on its position,
+  // not on the chunk, so each thread resolves its IPT pieces ONCE (element offset of the
+  // top-left corner, +x / +y corner strides, the two blend weights, the skip-tensor
+  // offset) and every chunk boundary is then 4 loads + blend + one LDS store per piece.
+  // (Recomputing them per chunk cost ~11k cycles per boundary in 64-bit address math -
+  // measured: 35 us of the fused up2 conv.)
+  // Two VGPRs per piece: g_off = element offset of the top-left corner (a multiple of 8)
+  // with flags in its 3 low bits (1: +x corner exists, 2: +y corner exists, 4: inside
+  // the image); g_w = the blend weights as 16-bit fixed point (lx | ly << 16).
+  int g_off[FUSED ? IPT : 1];
+  unsigned int g_w[FUSED ? IPT : 1];
+  if (FUSED) {
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+      const int q = tid + i * 256;
+      g_off[i] = 0; g_w[i] = 0;
+      if (q < IH * IW * 8) {
+        const int pos = q >> 3, part = q & 7;
+        const int py = pos / IW, px = pos - py * IW;
+        const int iy = oy0 - PAD + py, ix = ox0 - PAD + px;
+        if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+          const float sy = a.ry * (float)iy, sx = a.rx * (float)ix;
+          const int y0 = (int)sy, x0 = (int)sx;
+          const unsigned int wy = (unsigned int)((sy - (float)y0) * 65536.f + 0.5f);
+          const unsigned int wx = (unsigned int)((sx - (float)x0) * 65536.f + 0.5f);
+          g_w[i] = min(wx, 65535u) | (min(wy, 65535u) << 16);
+          g_off[i] = (((b * a.H + y0) * a.W + x0) * a.Cx + part * 8) | (x0 < a.W - 1 ? 1 : 0) |
+                     (y0 < a.H - 1 ? 2 : 0) | 4;
+        }
+      }
+    }
+  }
+  auto gather_fused = [&](int chunk) {
+    const unsigned short* xp = reinterpret_cast<const unsigned short*>(a.x);
+    const unsigned short* x2p = reinterpret_cast<const unsigned short*>(a.x2);
+    const int c0 = chunk * 64;
+    const bool skip = c0 < a.C2;  // chunk of the skip tensor x2: plain copy
+    const int dxs = a.Cx, dys = a.W * a.Cx;
+#pragma unroll 2
+    for (int i = 0; i < IPT; ++i) {
+      const int q = tid + i * 256;
+      if (q >= IH * IW * 8) continue;
+      const int pos = q >> 3, part = q & 7;
+      const int py = pos / IW, px = pos - py * IW;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (g_off[i] & 4) {
+        if (skip) {
+          const int iy = oy0 - PAD + py, ix = ox0 - PAD + px;
+          v = *reinterpret_cast<const uint4*>(x2p + ((b * a.Hin + iy) * a.Win + ix) * a.C2 + c0 + part * 8);
+        } else {
+          const unsigned short* p00 = xp + (g_off[i] & ~7) + (c0 - a.C2);
+          const int dx = (g_off[i] & 1) ? dxs : 0, dy = (g_off[i] & 2) ? dys : 0;
+          const uint4 q00 = *reinterpret_cast<const uint4*>(p00);
+          const uint4 q01 = *reinterpret_cast<const uint4*>(p00 + dx);
+          const uint4 q10 = *reinterpret_cast<const uint4*>(p00 + dy);
+          const uint4 q11 = *reinterpret_cast<const uint4*>(p00 + dy + dx);
+          v = blend_bf16x8(q00, q01, q10, q11, (float)(g_w[i] & 0xffff) * (1.f / 65536.f),
+                           (float)(g_w[i] >> 16) * (1.f / 65536.f));
+        }
+      }
+      *reinterpret_cast<uint4*>(in_tile + py * IROWB + px * POSB + part * 16) = v;
+    }
+  };
+
   // input patch of one 64-channel chunk.  !FUSED: plain 16-B loads, unrolled so they
   // can be parked in registers (prefetch).  FUSED: the 4-corner bilinear gather goes
   // straight to LDS piece by piece (rolled loop: keeps the live set small).
@@ -402,7 +504,8 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
   // prologue: W(0), W(1) on their way; patch of chunk 0
   issue_w(0, 0);
   if (nsteps > 1) issue_w(1, 1);
-  gather_in(0, true);
+  if (FUSED) gather_fused(0);
+  else gather_in(0, true);
   wait_vmcnt<0>();
   lds_barrier();
 
@@ -459,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
       if (prefetch) gather_in(chunk + 1, false);  // next patch -> registers
       if (tap == NT - 1 && !last_chunk) {
         lds_barrier();  // every wave is done with this chunk's patch
-        if (FUSED) gather_in(chunk + 1, true);
+        if (FUSED) gather_fused(chunk + 1);
         else store_in();
       }
       // W(step+1) must have landed in every wave's share before anyone reads it; only the
