@@ -81,4 +81,6 @@ def ptr(t):
 
 
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t of torch's current stream on the current device (raw handle: the
+    Python-level torch.cuda.current_stream() costs ~9 us per call, this ~0.3 us)."""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))

@@ -48,13 +48,16 @@ class _FoldedConv:
         self.key = None
         self.w = self.scale = self.shift = None
 
-    def _sources(self):
-        src = [self.conv.weight]
-        if self.conv.bias is not None:
-            src.append(self.conv.bias)
-        if self.bn is not None:
-            src += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
-        return src
+    def _key(self, dt):
+        # (storage pointer, in-place version) of every tensor the folded form depends on
+        c, bn = self.conv, self.bn
+        k = (dt, c.weight.data_ptr(), c.weight._version)
+        if c.bias is not None:
+            k += (c.bias._version,)
+        if bn is not None:
+            k += (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+                  bn.running_mean.data_ptr())
+        return k
 
     def _s2d(self, dt):
         """Stride-2 3x3/pad1 and 7x7/pad3 convs run on the LDS-tiled kernel through the
@@ -64,8 +67,7 @@ class _FoldedConv:
                 and c.padding[0] == c.kernel_size[0] // 2 and c.in_channels % 64 == 0)
 
     def get(self, dt):
-        src = self._sources()
-        key = (dt,) + tuple((t.data_ptr(), t._version) for t in src)
+        key = self._key(dt)
         if key != self.key:
             with torch.no_grad():
                 w32 = self.conv.weight.detach().float().contiguous()
