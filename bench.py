@@ -169,15 +169,15 @@ def main():
 
     # ---- roofline of the dominant kernel(s), from the HIP-event brackets -----------------
     n_conv, ms_conv = spans.get("bevencode", (0, 0.0))   # one bracket per step around the 18 conv launches
-    n_spl, ms_spl = spans.get("lift_splat_fwd", (0, 0.0))
+    n_spl, ms_spl = spans.get("lift_splat_level", (0, 0.0))   # one bracket around K3, K2, K4 (2 launches), K5
     conv_flops_step = bevencode_flops(X, Y) * B
     peak_tf = MFMA_BF16_TFLOPS if args.precision == "bf16" else MFMA_F32_TFLOPS
     conv_tf = conv_flops_step * args.steps / (ms_conv * 1e-3) / 1e12 if ms_conv else 0.0
     out_bytes = 2 if args.precision == "bf16" else 4
-    # the splat kernel's own algorithmic bytes: read depth+feat (tiny, L2) + write the grid once
-    splat_bytes_step = B * (C * Z * X * Y * out_bytes + 6 * fH * fW * (D + C) * 4)
-    spl_gbs = splat_bytes_step * args.steps / (ms_spl * 1e-3) / 1e9 if ms_spl else 0.0
+    # algorithmic bytes of the lift-splat level: trunk features in, BEV grid out
     l1_bytes_step = B * l1_bytes_per_frame(6, fH, fW, C, X, Y, Z, D, out_bytes)
+    splat_bytes_step = l1_bytes_step
+    spl_gbs = splat_bytes_step * args.steps / (ms_spl * 1e-3) / 1e9 if ms_spl else 0.0
 
     out = {
         "metric": "BEV frames/sec (6-cam 352x128 -> 200x200x64), full hot path: CamEncode lift + splat + BevEncode",
@@ -196,10 +196,13 @@ def main():
                      "bound": "mfma", "achieved": conv_tf, "peak": peak_tf, "unit": "TFLOP/s",
                      "frac": conv_tf / peak_tf, "traffic": pmc_traffic("conv_"), "launches": n_conv * 18,
                      "avg_us": ms_conv * 1e3 / max(n_conv * 18, 1), "flops_per_step": conv_flops_step},
-        "roofline_l1": {"kernel": "lift_splat_fwd_kernel", "bound": "hbm", "achieved": spl_gbs, "peak": HBM_PEAK_GBS,
+        "roofline_l1": {"kernel": "lift-splat level = points_to_voxels + depthnet_softmax + bucket_alloc + bucket_fill + "
+                                  "lift_splat_fwd (5 launches, one HIP-event bracket); `traffic` is lift_splat_fwd_kernel's own",
+                        "bound": "hbm", "achieved": spl_gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": spl_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("lift_splat_fwd_kernel"),
-                        "launches": n_spl,
-                        "avg_us": ms_spl * 1e3 / max(n_spl, 1), "bytes_per_launch": splat_bytes_step},
+                        "launches": n_spl * 5,
+                        "avg_us": ms_spl * 1e3 / max(n_spl * 5, 1), "level_us": ms_spl * 1e3 / max(n_spl, 1),
+                        "bytes_per_step": splat_bytes_step},
         "levels": {"L2_hot_path_fps": fps,
                    "L1_lift_splat_fps": frames / dt_l1, "L1_ms_per_step": dt_l1 / args.steps * 1e3,
                    "L1_algorithmic_GBs": l1_bytes_step * args.steps * world / dt_l1 / 1e9,

@@ -207,6 +207,31 @@ int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_packed, con
                         int B, int H, int W, int Cx, int C2, int up, int Cout, int head_n,
                         int relu, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Host-overhead reducers: the same kernels, several launches per call.  A caller
+ * that binds these issues ONE FFI call for the whole lift-splat level and ONE for
+ * the whole BevEncode instead of ~23 (each Python->C hop costs ~8-10 us of host
+ * time; on a slow host the step would otherwise become launch-bound).
+ */
+typedef struct lss_conv_launch {
+  const void* x; const void* x2; const void* w; const float* scale; const float* shift;
+  const void* residual; void* y; float* stats;
+  const float* head_w; const float* head_b; float* head_out;   /* kind 2 only */
+  int32_t B, H, W, Cx, C2, up, Cout, KH, KW, stride, pad, relu, dt, head_n;
+  int32_t kind;   /* 0 = lss_conv2d_fwd, 1 = lss_conv2d_s2_fwd, 2 = lss_conv2d_head_fwd */
+  int32_t reserved;
+} lss_conv_launch_t;
+/* Enqueue `n` conv launches in order on `stream`; returns the first non-zero code. */
+int lss_conv2d_sequence(const lss_conv_launch_t* launches, int n, void* stream);
+
+/* K3 -> K2 -> K4 -> K5 in one call (same arguments as the individual entries). */
+int lss_lift_splat_forward(const float* frustum, const float* inv_post_rots, const float* post_trans,
+                           const float* combine, const float* trans, const float* dx, const float* bx,
+                           const float* x, const float* w, const float* bias, int B, int N, int D,
+                           int fH, int fW, int Cin, int C, int X, int Y, int Z, int32_t* voxel,
+                           int32_t* vox_count, int32_t* vox_list, int32_t* entries, int32_t* cursor,
+                           float* depth, float* feat, void* bev, int layout, int math, void* stream);
+
 /* Layout / dtype conversion helpers between the reference's NCHW fp32 tensors
  * and the conv path's NHWC tensors. */
 int lss_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int dt,

@@ -914,3 +914,25 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
   else hipLaunchKernelGGL((conv_lds_kernel<2, 128, 0, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
   return lss_launch_status();
 }
+
+extern "C" int lss_conv2d_sequence(const lss_conv_launch_t* L, int n, void* stream) {
+  LSS_CHECK_PTR(L);
+  if (n < 0) return LSS_E_SHAPE;
+  for (int i = 0; i < n; ++i) {
+    const lss_conv_launch_t& c = L[i];
+    int rc;
+    if (c.kind == 0)
+      rc = lss_conv2d_fwd(c.x, c.x2, c.w, c.scale, c.shift, c.residual, c.y, c.stats, c.B, c.H, c.W, c.Cx,
+                          c.C2, c.up, c.Cout, c.KH, c.KW, c.stride, c.pad, c.relu, c.dt, stream);
+    else if (c.kind == 1)
+      rc = lss_conv2d_s2_fwd(c.x, c.w, c.scale, c.shift, c.residual, c.y, c.stats, c.B, c.H, c.W, c.Cx,
+                             c.Cout, c.KH, c.pad, c.relu, stream);
+    else if (c.kind == 2)
+      rc = lss_conv2d_head_fwd(c.x, c.x2, c.w, c.scale, c.shift, c.head_w, c.head_b, c.head_out, c.B, c.H,
+                               c.W, c.Cx, c.C2, c.up, c.Cout, c.head_n, c.relu, stream);
+    else
+      rc = LSS_E_LAYOUT;
+    if (rc != 0) return rc;
+  }
+  return 0;
+}

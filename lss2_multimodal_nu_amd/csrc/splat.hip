@@ -394,3 +394,21 @@ extern "C" int lss_lift_splat_bwd(const void* grad_bev, int layout, const int32_
 #undef LSS_BWD
   return lss_launch_status();
 }
+
+extern "C" int lss_lift_splat_forward(const float* frustum, const float* inv_post_rots,
+                                      const float* post_trans, const float* combine, const float* trans,
+                                      const float* dx, const float* bx, const float* x, const float* w,
+                                      const float* bias, int B, int N, int D, int fH, int fW, int Cin,
+                                      int C, int X, int Y, int Z, int32_t* voxel, int32_t* vox_count,
+                                      int32_t* vox_list, int32_t* entries, int32_t* cursor, float* depth,
+                                      float* feat, void* bev, int layout, int math, void* stream) {
+  int rc = lss_points_to_voxels(frustum, inv_post_rots, post_trans, combine, trans, dx, bx, B, N, D, fH,
+                                fW, X, Y, Z, voxel, vox_count, nullptr, stream);
+  if (rc) return rc;
+  rc = lss_depthnet_softmax_fwd(x, w, bias, B * N, Cin, fH * fW, D, C, depth, feat, math, stream);
+  if (rc) return rc;
+  rc = lss_bucket_points(voxel, depth, B * N * D * fH * fW, D, fH * fW, B * X * Y * Z, vox_count, vox_list,
+                         entries, cursor, stream);
+  if (rc) return rc;
+  return lss_lift_splat_fwd(feat, vox_list, entries, B, N, D, fH, fW, C, X, Y, Z, bev, layout, stream);
+}

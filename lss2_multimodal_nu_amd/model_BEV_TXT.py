@@ -211,16 +211,23 @@ class _LiftSplatMixin:
         if (self.D, fH, fW) != tuple(self.frustum.shape[:3]):
             raise RuntimeError("feature map %dx%d does not match the frustum %s"
                                % (fH, fW, tuple(self.frustum.shape[:3])))
-        ws, _ = self._index_points(rots, trans, intrins, post_rots, post_trans)
         dims = (B, BN // B, self.D, fH, fW, self.camC)
         ce = self.camencode
         if _needs_autograd(ce, x):
+            ws, _ = self._index_points(rots, trans, intrins, post_rots, post_trans)
             return _LiftSplatFn.apply(x.float(), ce.depthnet.weight, ce.depthnet.bias, ws, dims,
                                       self._nx_ints(), _PRECISIONS[ce.math], layout)
-        depth, feat = ce.depth_and_context(x)
-        ops.bucket_points(ws, depth)
-        with ops.region("lift_splat_fwd"):
-            return ops.lift_splat_fwd(feat, ws, dims, self._nx_ints(), layout, tag=None)
+        # inference: K3 -> K2 -> K4 -> K5 through one native call
+        dev = self.frustum.device
+        nx = self._nx_ints()
+        inv_pr, comb = self._calib_matrices(rots, intrins, post_rots)
+        inv_pr, comb, ptr, trn = self._upload(dev, inv_pr, comb, post_trans, trans)
+        ws = self._workspace(B * dims[1] * self.D * fH * fW, B * nx[0] * nx[1] * nx[2], dev)
+        with ops.region("lift_splat_level"):
+            bev, _, _ = ops.lift_splat_forward(self.frustum.detach(), inv_pr, ptr, comb, trn, self.dx.detach(),
+                                               self.bx.detach(), x.float().contiguous(), ce.depthnet.weight.detach(),
+                                               ce.depthnet.bias.detach(), ws, dims, nx, layout, _PRECISIONS[ce.math])
+        return bev
 
     def get_voxels(self, x, rots, trans, intrins, post_rots, post_trans):
         return self._lift_splat(x, rots, trans, intrins, post_rots, post_trans, ops.BEV_NCHW_F32)

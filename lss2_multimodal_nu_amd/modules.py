@@ -237,6 +237,7 @@ class BevEncode(nn.Module):
             nn.Conv2d(128, outC, kernel_size=1, padding=0),
         )
         self.precision = precision
+        self._plans = {}
         self._stem = _FoldedConv(self.conv1, self.bn1)
         self._up2a = _FoldedConv(self.up2[1], self.up2[2])
         self._up2b = _FoldedConv(self.up2[4], None)
@@ -248,10 +249,51 @@ class BevEncode(nn.Module):
         x = self.up1(x, x1)
         return self.up2(x)
 
+    def invalidate_plan(self):
+        """Drop the cached launch lists (called whenever parameters may have changed)."""
+        self._plans = {}
+
+    def train(self, mode=True):
+        self.invalidate_plan()
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate_plan()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.invalidate_plan()
+        return super().load_state_dict(*a, **k)
+
+    def _plan_stamp(self):
+        return tuple(f._key(0)[1:] for f in (self._stem, self._up2a, self._up2b, self.up1._f0, self.up1._f1)) + \
+            tuple(b._f1._key(0)[1:] + b._f2._key(0)[1:] for l in (self.layer1, self.layer2, self.layer3) for b in l)
+
     def forward_nhwc(self, x, dt):
-        """HIP path: x (B,X,Y,inC) channels-last activations in dt -> (B,outC,X,Y) fp32 NCHW."""
+        """HIP path: x (B,X,Y,inC) channels-last activations in dt -> (B,outC,X,Y) fp32 NCHW.
+        bf16: the 18 launches are recorded once per input shape and replayed with one native
+        call (same kernels, same order; ~150 us less host time per step)."""
         with ops.region("bevencode"):
-            return self._forward_nhwc(x, dt)
+            if dt != ops.DT_BF16 or ops._recorder is not None or os.environ.get("LSS_NO_PLAN"):
+                return self._forward_nhwc(x, dt)
+            key = (tuple(x.shape), x.device)
+            ent = self._plans.get(key)
+            self._calls = getattr(self, "_calls", 0) + 1
+            if ent is not None and self._calls % 64 == 0 and ent[1] != self._plan_stamp():
+                ent = None  # parameters were modified in place since the plan was built
+            if ent is None:
+                rec = ops.ConvRecorder()
+                ops.set_recorder(rec)
+                try:
+                    out = self._forward_nhwc(x, dt)
+                finally:
+                    ops.set_recorder(None)
+                self._plans[key] = (ops.ConvPlan(rec, x, out), self._plan_stamp())
+                return out.clone()  # the recorded output buffer stays with the plan
+            out = torch.empty(x.shape[0], self.up2[4].out_channels, x.shape[1], x.shape[2],
+                              dtype=torch.float32, device=x.device)
+            ent[0].run(x, out)
+            return out
 
     def _forward_nhwc(self, x, dt):
         x = self._stem.run(x, dt, relu=True)

@@ -67,6 +67,58 @@ def region(tag):
     return _timed(tag, coarse=True)
 
 
+class ConvRecorder:
+    """Collects the conv launches of one eager pass (pointers + shapes) together with the
+    tensors that must outlive them; `ConvPlan` replays the list with ONE native call."""
+
+    def __init__(self):
+        self.launches = []
+        self.keep = []
+
+    def add(self, kind, keep, **f):
+        self.launches.append((kind, f))
+        self.keep.extend(t for t in keep if t is not None)
+
+
+_recorder = None
+
+
+def set_recorder(r):
+    global _recorder
+    _recorder = r
+
+
+class ConvPlan:
+    def __init__(self, rec, x_in, out):
+        n = len(rec.launches)
+        self.n = n
+        self.arr = (N.ConvLaunch * n)()
+        self.keep = rec.keep
+        self.in_slots, self.out_slots = [], []
+        pin, pout = x_in.data_ptr(), out.data_ptr()
+        for i, (kind, f) in enumerate(rec.launches):
+            c = self.arr[i]
+            c.kind = kind
+            for k, v in f.items():
+                setattr(c, k, v.data_ptr() if isinstance(v, torch.Tensor) else (v if v is not None else None))
+            for name in ("x", "x2", "residual"):
+                if getattr(c, name) == pin:
+                    self.in_slots.append((i, name))
+            for name in ("y", "head_out"):
+                if getattr(c, name) == pout:
+                    self.out_slots.append((i, name))
+        if not self.in_slots or not self.out_slots:
+            raise RuntimeError("conv plan: input / output tensor not found among the recorded launches")
+
+    def run(self, x_in, out):
+        pin, pout = x_in.data_ptr(), out.data_ptr()
+        for i, name in self.in_slots:
+            setattr(self.arr[i], name, pin)
+        for i, name in self.out_slots:
+            setattr(self.arr[i], name, pout)
+        N.check(N.lib().lss_conv2d_sequence(self.arr, self.n, N.stream()), "lss_conv2d_sequence")
+
+
 class SplatWorkspace:
     """Index buffers of one (B,N,D,fH,fW | X,Y,Z) problem, reused across steps.
 
@@ -177,6 +229,39 @@ def lift_splat_fwd(feat, ws, dims, nx, layout=BEV_NCHW_F32, tag="lift_splat_fwd"
     return out
 
 
+def lift_splat_forward(frustum, inv_post_rots, post_trans, combine, trans, dx, bx, x, weight, bias, ws, dims, nx,
+                       layout=BEV_NCHW_F32, math=DT_F32):
+    """K3 -> K2 -> K4 -> K5 with ONE native call (inference path).  Returns (bev, depth, feat)."""
+    B, Ncam, D, fH, fW, C = dims
+    X, Y, Z = nx
+    for t, name, shp in ((frustum, "frustum", (D, fH, fW, 3)), (inv_post_rots, "inv_post_rots", (B, Ncam, 3, 3)),
+                         (combine, "combine", (B, Ncam, 3, 3)), (post_trans, "post_trans", (B, Ncam, 3)),
+                         (trans, "trans", (B, Ncam, 3)), (dx, "dx", (3,)), (bx, "bx", (3,))):
+        _f32c(t, name, shp)
+    Cin = x.shape[1]
+    _f32c(x, "x", (B * Ncam, Cin, fH, fW))
+    w2 = weight.reshape(weight.shape[0], -1)
+    _f32c(w2, "depthnet.weight", (D + C, Cin))
+    _f32c(bias, "depthnet.bias", (D + C,))
+    if ws.P != B * Ncam * D * fH * fW or ws.nvox != B * X * Y * Z:
+        raise ValueError("workspace does not match dims")
+    dev = x.device
+    depth = torch.empty(B * Ncam, D, fH, fW, dtype=torch.float32, device=dev)
+    feat = torch.empty(B * Ncam, fH, fW, C, dtype=torch.float32, device=dev)
+    if layout == BEV_NCHW_F32:
+        bev = torch.empty(B, Z * C, X, Y, dtype=torch.float32, device=dev)
+        out = bev
+    else:
+        bev = torch.empty(B, X, Y, Z * C, dtype=torch.float32 if layout == BEV_NHWC_F32 else torch.bfloat16, device=dev)
+        out = bev.permute(0, 3, 1, 2)
+    N.check(N.lib().lss_lift_splat_forward(
+        N.ptr(frustum), N.ptr(inv_post_rots), N.ptr(post_trans), N.ptr(combine), N.ptr(trans), N.ptr(dx), N.ptr(bx),
+        N.ptr(x), N.ptr(w2), N.ptr(bias), B, Ncam, D, fH, fW, Cin, C, X, Y, Z, N.ptr(ws.voxel), N.ptr(ws.vox_count),
+        N.ptr(ws.vox_list), N.ptr(ws.entries), N.ptr(ws.cursor), N.ptr(depth), N.ptr(feat), N.ptr(bev), layout, math,
+        N.stream()), "lss_lift_splat_forward")
+    return out, depth, feat
+
+
 def lift_splat_bwd(grad_bev, voxel, depth, feat, dims, nx):
     """K7.  grad_bev logical (B, Z*C, X, Y), contiguous or channels_last fp32.
     Returns g_logits (BN, D+C, fH, fW)."""
@@ -252,6 +337,10 @@ def conv2d_nhwc(x, w_packed, ksize, stride, pad, scale=None, shift=None, residua
         raise ValueError("residual must match the output")
     if stats is not None:
         _f32c(stats, "stats", (2 * Cout,))
+    if _recorder is not None:
+        _recorder.add(0, (x, x2, w_packed, scale, shift, residual, y, stats), x=x, x2=x2, w=w_packed, scale=scale,
+                      shift=shift, residual=residual, y=y, stats=stats, B=B, H=H, W=W, Cx=Cx, C2=C2, up=up, Cout=Cout,
+                      KH=KH, KW=KW, stride=stride, pad=pad, relu=1 if relu else 0, dt=dt)
     with _timed(tag):
         N.check(N.lib().lss_conv2d_fwd(N.ptr(x), N.ptr(x2), N.ptr(w_packed), N.ptr(scale), N.ptr(shift),
                                        N.ptr(residual), N.ptr(y), N.ptr(stats), B, H, W, Cx, C2, up, Cout,
@@ -288,6 +377,10 @@ def conv2d_s2_nhwc(x, w_s2d, K, pad, scale=None, shift=None, residual=None, relu
         raise ValueError("residual must match the output")
     if stats is not None:
         _f32c(stats, "stats", (2 * Cout,))
+    if _recorder is not None:
+        _recorder.add(1, (x, w_s2d, scale, shift, residual, y, stats), x=x, w=w_s2d, scale=scale, shift=shift,
+                      residual=residual, y=y, stats=stats, B=B, H=H, W=W, Cx=Cx, Cout=Cout, KH=K, KW=K, stride=2,
+                      pad=pad, relu=1 if relu else 0, dt=DT_BF16)
     with _timed(tag):
         N.check(N.lib().lss_conv2d_s2_fwd(N.ptr(x), N.ptr(w_s2d), N.ptr(scale), N.ptr(shift), N.ptr(residual),
                                           N.ptr(y), N.ptr(stats), B, H, W, Cx, Cout, K, pad, 1 if relu else 0,
@@ -309,6 +402,10 @@ def conv3x3_head_nchw(x, w_packed, scale, shift, head_w, head_b, x2=None, up=1, 
     _f32c(scale, "scale", (Cout,))
     _f32c(shift, "shift", (Cout,))
     out = torch.empty(B, n, H * up, W * up, dtype=torch.float32, device=x.device)
+    if _recorder is not None:
+        _recorder.add(2, (x, x2, w_packed, scale, shift, head_w, head_b, out), x=x, x2=x2, w=w_packed, scale=scale,
+                      shift=shift, head_w=head_w, head_b=head_b, head_out=out, B=B, H=H, W=W, Cx=Cx, C2=C2, up=up,
+                      Cout=Cout, KH=3, KW=3, stride=1, pad=1, relu=1 if relu else 0, dt=DT_BF16, head_n=n)
     with _timed(tag):
         N.check(N.lib().lss_conv2d_head_fwd(N.ptr(x), N.ptr(x2), N.ptr(w_packed), N.ptr(scale), N.ptr(shift),
                                             N.ptr(head_w), N.ptr(head_b), N.ptr(out), B, H, W, Cx, C2, up, Cout, n,
