@@ -113,6 +113,37 @@ def test_lss_forward_hires_config5_shapes():
     assert float((out.cpu() - ref).norm() / ref.norm()) < 4e-2
 
 
+def test_plan_replay_equals_eager(monkeypatch):
+    """The recorded launch plan (2nd+ call) must reproduce the eager launches bit for bit, follow
+    new inputs, and be rebuilt when weights change."""
+    torch.manual_seed(3)
+    B = 2
+    m = L.compile_model_lss(B, GRID, AUG, 4, precision="bf16")
+    randomize_bn(m)
+    m = m.cuda().eval()
+    xs = [torch.randn(B * 6, 512, 8, 22, device="cuda") for _ in range(3)]
+    calibs = [lo.synthetic_rig(B, train_aug=True, seed=s) for s in (1, 2, 3)]
+    with torch.no_grad():
+        planned = [m(x, *c).clone() for x, c in zip(xs, calibs)]      # call 1 records, 2-3 replay
+        again = m(xs[0], *calibs[0]).clone()
+        monkeypatch.setenv("LSS_NO_PLAN", "1")
+        eager = [m(x, *c).clone() for x, c in zip(xs, calibs)]
+        monkeypatch.delenv("LSS_NO_PLAN")
+        for p_, e_ in zip(planned, eager):
+            assert torch.equal(p_, e_)
+        assert torch.equal(again, eager[0])
+        # in-place weight change + explicit invalidation -> new plan, new result
+        m.bevencode.up2[4].bias.add_(1.0)
+        m.bevencode.invalidate_plan()
+        shifted = m(xs[0], *calibs[0])
+        assert torch.allclose(shifted, eager[0] + 1.0, atol=1e-5)
+        # load_state_dict invalidates by itself
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        sd["bevencode.up2.4.bias"] -= 1.0
+        m.load_state_dict(sd)
+        assert torch.allclose(m(xs[0], *calibs[0]), eager[0], atol=1e-5)
+
+
 def test_bevencode_and_up_modules_vs_oracle(golden):
     torch.manual_seed(2)
     be = L.BevEncode(64, 4, precision="fp32")
