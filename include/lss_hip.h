@@ -185,7 +185,8 @@ int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packed,
                    int Cout, int KH, int KW, int stride, int pad, int relu, int dt,
                    void* stream);
 
-/* Stride-2 convs (3x3 pad 1, 7x7 pad 3; bf16) on the LDS-tiled MFMA kernel: the
+/* Stride-2 convs (3x3 pad 1, 7x7 pad 3, and 1x1 pad 0 with the plain weight pack;
+ * bf16) on the LDS-tiled MFMA kernel: the
  * conv is evaluated as a stride-1 conv over the 4 parity phases of the input
  * (space-to-depth folded into the operand gather).  Weights are arranged
  * [tap'][Cout][phase*Cin + ci] by lss_conv2d_pack_weights_s2d.  Same epilogue as

@@ -535,8 +535,8 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
       // slab two steps ahead: tap+2 of this chunk, or tap+2-NT of the next one
-      const int t2 = tap + 2 < NT ? tap + 2 : tap + 2 - NT;
-      const int c2 = tap + 2 < NT ? chunk : chunk + 1;
+      const int t2 = (tap + 2) % NT;
+      const int c2 = chunk + (tap + 2) / NT;
       const bool more = c2 < nchunks;
       const bool prefetch = !FUSED && tap == PF_TAP && !last_chunk;
       const int slot2 = slot >= 1 ? slot - 1 : 2;  // (slot + 2) % 3
@@ -855,13 +855,15 @@ extern "C" int lss_conv2d_s2_fwd(const void* x, const void* w_s2d, const float* 
                                  void* stream) {
   LSS_CHECK_PTR(x); LSS_CHECK_PTR(w_s2d); LSS_CHECK_PTR(y);
   LSS_CHECK_POS(B); LSS_CHECK_POS(H); LSS_CHECK_POS(W); LSS_CHECK_POS(Cx); LSS_CHECK_POS(Cout);
-  if (!((K == 3 && pad == 1) || (K == 7 && pad == 3))) return LSS_E_SHAPE;
+  if (!((K == 3 && pad == 1) || (K == 7 && pad == 3) || (K == 1 && pad == 0))) return LSS_E_SHAPE;
   if (Cx % 64 != 0) return LSS_E_SHAPE;
   ConvArgs a;
   a.x = x; a.x2 = nullptr; a.w = w_s2d; a.scale = scale; a.shift = shift; a.residual = residual;
   a.y = y; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cx = Cx; a.C2 = 0; a.up = 1;
-  a.Hin = H; a.Win = W; a.Cin = 4 * Cx;
+  // K = 1: only parity phase (0,0) is ever read, so the K loop runs over that phase alone
+  // and the weights are the plain [1][Cout][Cx] pack
+  a.Hin = H; a.Win = W; a.Cin = K == 1 ? Cx : 4 * Cx;
   a.Cout = Cout; a.KH = K; a.KW = K; a.stride = 2; a.pad = pad;
   a.Ho = (H + 2 * pad - K) / 2 + 1;
   a.Wo = (W + 2 * pad - K) / 2 + 1;
@@ -874,7 +876,8 @@ extern "C" int lss_conv2d_s2_fwd(const void* x, const void* w_s2d, const float* 
   a.ry = a.rx = 0.f;
   hipStream_t st = lss_stream(stream);
   if (K == 7) launch_conv_lds<2, 4, 4, 2>(a, st);
-  else launch_conv_lds<2, 2, 2, 1>(a, st);
+  else if (K == 3) launch_conv_lds<2, 2, 2, 1>(a, st);
+  else launch_conv_lds<2, 1, 1, 0>(a, st);
   return lss_launch_status();
 }
 

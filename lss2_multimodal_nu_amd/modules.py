@@ -63,7 +63,7 @@ class _FoldedConv:
         """Stride-2 3x3/pad1 and 7x7/pad3 convs run on the LDS-tiled kernel through the
         phase-plane (space-to-depth) weight arrangement (bf16 path only)."""
         c = self.conv
-        return (dt == ops.DT_BF16 and c.stride[0] == 2 and c.kernel_size in ((3, 3), (7, 7))
+        return (dt == ops.DT_BF16 and c.stride[0] == 2 and c.kernel_size in ((1, 1), (3, 3), (7, 7))
                 and c.padding[0] == c.kernel_size[0] // 2 and c.in_channels % 64 == 0)
 
     def get(self, dt):
@@ -71,8 +71,9 @@ class _FoldedConv:
         if key != self.key:
             with torch.no_grad():
                 w32 = self.conv.weight.detach().float().contiguous()
-                self.w = ops.pack_conv_weight_s2d(w32, self.conv.padding[0]) if self._s2d(dt) \
-                    else ops.pack_conv_weight(w32, dt)
+                # (the 1x1/2 conv reads parity phase (0,0) only: plain pack)
+                self.w = ops.pack_conv_weight_s2d(w32, self.conv.padding[0]) \
+                    if (self._s2d(dt) and self.conv.kernel_size[0] > 1) else ops.pack_conv_weight(w32, dt)
                 if self.bn is not None:
                     inv = torch.rsqrt(self.bn.running_var.float() + self.bn.eps)
                     self.scale = (self.bn.weight.float() * inv).contiguous()

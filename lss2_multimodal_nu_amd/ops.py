@@ -362,10 +362,12 @@ def pack_conv_weight_s2d(w_oihw, pad):
 
 def conv2d_s2_nhwc(x, w_s2d, K, pad, scale=None, shift=None, residual=None, relu=False, stats=None,
                    tag="conv2d_fwd"):
-    """Stride-2 K x K conv (3/pad 1 or 7/pad 3), bf16 NHWC, on the LDS-tiled kernel."""
+    """Stride-2 K x K conv (3/pad 1, 7/pad 3 with s2d-packed weights; 1/pad 0 with the plain
+    pack), bf16 NHWC, on the LDS-tiled kernel."""
     B, H, W, Cx = x.shape
     taps, Cout, C4 = w_s2d.shape
-    if x.dtype != torch.bfloat16 or not x.is_contiguous() or w_s2d.dtype != torch.bfloat16 or C4 != 4 * Cx:
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or w_s2d.dtype != torch.bfloat16 \
+            or C4 != (Cx if K == 1 else 4 * Cx):
         raise ValueError("conv2d_s2_nhwc operands must be contiguous bf16 with s2d-packed weights")
     Ho, Wo = (H + 2 * pad - K) // 2 + 1, (W + 2 * pad - K) // 2 + 1
     y = torch.empty(B, Ho, Wo, Cout, dtype=torch.bfloat16, device=x.device)

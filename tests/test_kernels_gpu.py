@@ -384,6 +384,8 @@ S2_CONVS = [  # B, H, W, Cin, Cout, k, relu, residual
     (2, 50, 50, 128, 256, 3, False, True),
     (1, 33, 40, 64, 64, 3, True, False),
     (1, 37, 18, 128, 200, 7, False, False),
+    (2, 50, 50, 128, 256, 1, False, False),
+    (1, 21, 33, 64, 128, 1, False, False),
 ]
 
 
@@ -406,7 +408,7 @@ def test_k8_stride2_conv_phase_plane_path(ops, cfg):
         ref = ref.relu()
     xg = ops.nchw_to_nhwc(x.cuda(), 1)
     resg = ops.nchw_to_nhwc(res.cuda(), 1) if use_res else None
-    wp = ops.pack_conv_weight_s2d(w.cuda(), pad)
+    wp = ops.pack_conv_weight_s2d(w.cuda(), pad) if k > 1 else ops.pack_conv_weight(w.cuda(), 1)
     stats = torch.zeros(2 * Cout, device="cuda")
     y = ops.conv2d_s2_nhwc(xg, wp, k, pad, scale.cuda(), shift.cuda(), resg, relu, stats)
     out = ops.nhwc_to_nchw(y, 1).cpu()

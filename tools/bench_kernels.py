@@ -55,9 +55,9 @@ def main():
         for name, H, W, Cx, Cout, k, st, pad, C2, up, res in CONVS:
             x = torch.randn(B, H, W, Cx, device="cuda").to(torch.bfloat16)
             x2 = torch.randn(B, H * up, W * up, C2, device="cuda").to(torch.bfloat16) if C2 else None
-            s2 = st == 2 and k in (3, 7)
+            s2 = st == 2 and k in (1, 3, 7)
             wraw = torch.randn(Cout, Cx + C2, k, k, device="cuda") * 0.05
-            w = ops.pack_conv_weight_s2d(wraw, pad) if s2 else ops.pack_conv_weight(wraw, dt)
+            w = ops.pack_conv_weight_s2d(wraw, pad) if (s2 and k > 1) else ops.pack_conv_weight(wraw, dt)
             sc, sh = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda")
             Ho = (H * up + 2 * pad - k) // st + 1
             Wo = (W * up + 2 * pad - k) // st + 1
