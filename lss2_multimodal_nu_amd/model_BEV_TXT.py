@@ -115,6 +115,8 @@ class _LiftSplatMixin:
         self.use_quickcumsum = True  # kept for API compatibility; both settings take the HIP path
         self._nx_cache = None
         self._ws = {}
+        self._stage = None
+        self._stage_i = 0
 
     # -- grid bookkeeping ---------------------------------------------------
     def create_frustum(self):
@@ -146,15 +148,38 @@ class _LiftSplatMixin:
         """inv(post_rots) and rots @ inv(intrins), computed with torch ON THE HOST:
         the voxel index of a point must equal the reference CPU path's bit for
         bit, and only the host LAPACK reproduces its 3x3 inverses.
-        CPU calibration tensors (what a DataLoader hands over) cost no sync."""
-        r, i, p = (t.detach().float().cpu() for t in (rots, intrins, post_rots))
-        return torch.inverse(p), r.matmul(torch.inverse(i))
+        CPU calibration tensors (what a DataLoader hands over) cost no sync.
+        Both inverses go through ONE flattened (2*B*N, 3, 3) call: bitwise the same
+        matrices as the reference's two 4-D calls (tests/test_modules_cpu.py), ~8x less
+        host time."""
+        r, i, p = (t.detach().float().cpu().reshape(-1, 3, 3) for t in (rots, intrins, post_rots))
+        n = p.shape[0]
+        inv = torch.inverse(torch.cat([p, i]))
+        shape = tuple(rots.shape)
+        return inv[:n].view(shape), torch.bmm(r, inv[n:]).view(shape)
 
     def _upload(self, device, *ts):
-        # one pinned staging block per call: torch's caching host allocator keeps it
-        # alive until the async copy has run, so back-to-back steps never race on it
-        flat = torch.cat([t.detach().float().reshape(-1).cpu() for t in ts]).pin_memory()
-        d = flat.to(device, non_blocking=True)
+        """Host tensors -> one pinned staging block -> one async H2D copy -> device views.
+        The staging blocks form a small ring guarded by events, so a host that runs many
+        steps ahead of the GPU never overwrites a block whose copy has not executed yet."""
+        total = sum(t.numel() for t in ts)
+        ring = self._stage
+        if ring is None or ring[0][0].numel() != total:
+            ring = self._stage = [[torch.empty(total, dtype=torch.float32).pin_memory(), None] for _ in range(8)]
+            self._stage_i = 0
+        self._stage_i = (self._stage_i + 1) % len(ring)
+        buf, ev = ring[self._stage_i]
+        if ev is not None:
+            ev.synchronize()  # normally long done
+        o = 0
+        for t in ts:
+            n = t.numel()
+            buf[o:o + n].copy_(t.detach().reshape(-1))
+            o += n
+        d = buf.to(device, non_blocking=True)
+        if ring[self._stage_i][1] is None:
+            ring[self._stage_i][1] = torch.cuda.Event()
+        ring[self._stage_i][1].record()
         out, o = [], 0
         for t in ts:
             out.append(d[o:o + t.numel()].view(t.shape))

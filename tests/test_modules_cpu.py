@@ -95,6 +95,20 @@ def test_up_container_loads_reference_state(golden, name):
     np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-4, atol=1e-5)
 
 
+def test_host_calibration_matrices_equal_reference_expressions(lss):
+    """The flattened single-call form must give bitwise the matrices of the reference's
+    `torch.inverse(post_rots)` and `rots.matmul(torch.inverse(intrins))` (ref :60,:66)."""
+    for seed, aug in ((0, False), (1, True), (2, True)):
+        r, t, i, pr, pt = lo.synthetic_rig(3, train_aug=aug, seed=seed)
+        inv_pr, comb = lss._calib_matrices(r, i, pr)
+        assert torch.equal(inv_pr, torch.inverse(pr))
+        assert torch.equal(comb, r.matmul(torch.inverse(i)))
+    g = torch.Generator().manual_seed(5)
+    r, i, pr = (torch.randn(2, 6, 3, 3, generator=g) for _ in range(3))
+    inv_pr, comb = lss._calib_matrices(r, i, pr)
+    assert torch.equal(inv_pr, torch.inverse(pr)) and torch.equal(comb, r.matmul(torch.inverse(i)))
+
+
 def test_trunk_slot_rejects_raw_images(lss):
     with pytest.raises(RuntimeError):
         lss.encoder(torch.zeros(2, 6, 3, 128, 352))
