@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="samples per GPU per step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="config2", choices=["config2", "hires"],
+                    help="config2 = BASELINE configs[1] (default, the metric's workload); hires = configs[4] "
+                         "per-GPU shapes (6 x 704x256, D=60, 400x400 BEV, batch 2/GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-steps", type=int, default=8)
@@ -116,14 +119,20 @@ def main():
     from oracle import lss_oracle as lo  # input generator + cpu_baseline leg only
 
     B = args.batch
+    grid, aug, fH, fW, X, Y = GRID, AUG, 8, 22, 200, 200
+    if args.workload == "hires":
+        grid = dict(xbound=[-50.0, 50.0, 0.25], ybound=[-50.0, 50.0, 0.25], zbound=[-10.0, 10.0, 20.0],
+                    dbound=[1.0, 61.0, 1.0])
+        aug, fH, fW, X, Y = {"final_dim": (256, 704), "Ncams": 6}, 16, 44, 400, 400
+        B = 2 if args.batch == 4 else args.batch
     torch.manual_seed(0)
-    model = L.compile_model_lss(B, GRID, AUG, 4, precision=args.precision).to(dev).eval()
-    D, fH, fW, C = model.D, 8, 22, model.camC
-    X, Y, Z = 200, 200, 1
+    model = L.compile_model_lss(B, grid, aug, 4, precision=args.precision).to(dev).eval()
+    D, C = model.D, model.camC
+    Z = 1
     # per-rank shard of the global batch: different samples (seeded by rank), same shapes
     g = torch.Generator().manual_seed(1234 + rank)
     feats = torch.randn(B * 6, 512, fH, fW, generator=g).to(dev)
-    calib = lo.synthetic_rig(B, train_aug=True, seed=rank)  # CPU tensors, as a DataLoader delivers them
+    calib = lo.synthetic_rig(B, final_dim=aug["final_dim"], train_aug=True, seed=rank)  # CPU tensors, as a DataLoader delivers them
 
     def barrier():
         if dist is not None:
@@ -186,9 +195,11 @@ def main():
         "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32",
         "data": "synthetic (seeded N(0,1) trunk features 6x512x8x22 per frame, nuScenes-like 6-camera rig "
                 "with train-time augmentation, random-init weights)",
-        "config": {"workload": "BASELINE configs[1]: model_BEV_TXT LSS hot path, batch=%d/GPU, 6 cams 352x128, "
-                               "D=41, 200x200x64 BEV -> BevEncode -> 200x200x4, trunk (EfficientNet) not included: "
-                               "features are the input" % B,
+        "config": {"workload": ("BASELINE configs[1]: model_BEV_TXT LSS hot path, batch=%d/GPU, 6 cams 352x128, "
+                                "D=41, 200x200x64 BEV -> BevEncode -> 200x200x4, trunk (EfficientNet) not included: "
+                                "features are the input" % B) if args.workload == "config2" else
+                               ("BASELINE configs[4] per-GPU shapes: batch=%d/GPU, 6 cams 704x256, D=60, 400x400x64 BEV "
+                                "-> BevEncode -> 400x400x4" % B),
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d (sample-sharded, no collective)" % world,
                    "precision": args.precision, "calibration": "CPU tensors per step; 3x3 inverses on host (exact-index contract), 1.7 KB H2D"},
         "roofline": {"kernel": "conv_lds_kernel (+3 conv_direct_kernel): the 18 BevEncode launches of a step, one HIP-event "
@@ -210,11 +221,11 @@ def main():
     }
 
     # ---- training step (fwd + bwd + Adam, RCCL all-reduce of one flat gradient bucket) ----
-    if not args.no_train:
+    if not args.no_train and args.workload == "config2":
         out["train"] = train_leg(args, model, feats, calib, dev, dist, world, B)
 
     # ---- CPU baseline: the oracle (op-for-op torch port of the reference) on this host ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "config2":
         out["cpu_baseline"] = cpu_baseline(model, feats, calib, B)
 
     if rank == 0:
