@@ -245,3 +245,9 @@ def test_training_step_runs(model):
     loss.backward()
     opt.step()
     assert torch.isfinite(loss) and not torch.equal(w0, m.camencode.depthnet.weight.detach())
+
+
+def test_graft_entry_smoke():
+    """The driver's smoke() entry point must keep working (it runs the whole hot path)."""
+    import __graft_entry__ as ge
+    ge.smoke()
