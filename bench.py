@@ -247,14 +247,27 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     weight = torch.tensor([1.0, 10.0, 5.0, 10.0], device=dev)         # ref: src/tools.py:234
 
     def loss_fn(y):
-        return torch.nn.functional.cross_entropy(y, tgt, weight=weight)
+        return torch.nn.functional.cross_entropy(y.float(), tgt, weight=weight)
+
+    amp = args.precision == "bf16"  # bf16 autocast for the (library) BevEncode convs, fp32 master weights
+
+    class _Amp(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, *a):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                return self.inner(*a)
+
+    wrapped = _Amp(m)
 
     def one():
         if dist is not None:
-            dp.train_step(m, bucket, opt, loss_fn, (feats,) + tuple(calib))
+            dp.train_step(wrapped, bucket, opt, loss_fn, (feats,) + tuple(calib))
         else:
             opt.zero_grad(set_to_none=True)
-            loss_fn(m(feats, *calib)).backward()
+            loss_fn(wrapped(feats, *calib)).backward()
             torch.nn.utils.clip_grad_norm_(bucket.params, 5.0)      # ref: train.py:64
             opt.step()
 
@@ -275,7 +288,9 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     dt = float(dt[0])
     return {"samples_per_s": args.train_steps * B * world / dt, "ms_per_step": dt / args.train_steps * 1e3,
             "steps": args.train_steps, "grad_bucket_MB": bucket.numel * 4 / 1e6,
-            "note": "lift-splat fwd/bwd native HIP; BevEncode fwd/bwd + BN batch stats via torch/MIOpen (not yet native)"}
+            "amp_bf16": amp,
+            "note": "lift-splat fwd/bwd native HIP (fp32); BevEncode fwd/bwd + BN batch stats via torch/MIOpen "
+                    "(not yet native), bf16 autocast when --precision bf16"}
 
 
 def host_cores():
