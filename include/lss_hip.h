@@ -123,6 +123,38 @@ int lss_depthnet_softmax_fwd(const float* x, const float* w, const float* bias,
                              float* depth, float* feat, int math, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * K2v  two-source CamEncode of the vovnet models: depth logits from the depth
+ *      head's hidden map, context from `feat_proj` over the trunk's C3 map.
+ * replaces: src/model_vovnet_transformer.py:82,86-87 (StandardDepthNet's last 1x1
+ *           conv + softmax), :31,39 (MultiScaleDepthNet's 1x1 convs, raw logits),
+ *           :97,108 (CamEncodeV2.feat_proj); the outer product of :116-120 is
+ *           NOT materialised (K5 forms it in registers).
+ *   x_depth (BN*HW, Cd) NHWC activations of the depth head's 3x3 conv, dtype `dt`
+ *   w_depth (D, Cd) fp32, b_depth (D) fp32
+ *   x_feat  (BN, Cf, HW) fp32 NCHW trunk map, w_feat (C, Cf), b_feat (C); all three
+ *           may be NULL with C = 0 (logits only)
+ *   softmax 1: depth = softmax over D; 0: depth = raw logits
+ *   depth   (BN, D, HW) fp32 out;  feat (BN*HW, C) fp32 out (channels-last rows)
+ *   Cd % 64 == 0, Cf % 64 == 0; D <= 64; C in {0, 49..64, 113..128}
+ * Math: f32 MFMA (exact fp32 FMA chains), bf16 inputs widened exactly.
+ */
+int lss_camencode_v2_fwd(const void* x_depth, int dt, const float* w_depth, const float* b_depth,
+                         int Cd, const float* x_feat, const float* w_feat, const float* b_feat,
+                         int Cf, int BN, int HW, int D, int C, int softmax, float* depth,
+                         float* feat, void* stream);
+
+/* MultiScaleDepthNet tail.
+ * replaces: src/model_vovnet_transformer.py:61-70 (F.interpolate bilinear
+ *           align_corners=False, cat, fusion 1x1 conv + BatchNorm(eval) + ReLU, softmax)
+ *   d3 (BN, D, H, W), d4 (BN, D, H4, W4) fp32 raw logits; w_fusion (D, 2D) fp32;
+ *   scale, shift (D) fp32 = eval BatchNorm folded with the conv bias; D <= 64
+ *   depth (BN, D, H, W) fp32 out
+ */
+int lss_depth_fuse_softmax_fwd(const float* d3, const float* d4, const float* w_fusion,
+                               const float* scale, const float* shift, int BN, int D, int H, int W,
+                               int H4, int W4, float* depth, void* stream);
+
+/* ---------------------------------------------------------------------------
  * K5/K6  fused lift + splat: bev[v, c] = sum_{p in voxel v} w[p] * feat[row(p), c]
  *        (w = the depth weight K4 stored next to the point id)
  * replaces: src/modules.py:84 (outer product), src/model_BEV_TXT.py:80,89

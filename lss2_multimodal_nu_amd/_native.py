@@ -25,6 +25,8 @@ SIGNATURES = {
     "lss_geom_to_voxels": (_i, [_vp, _vp, _vp] + [_i] * 5 + [_vp, _vp, _vp]),
     "lss_bucket_points": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lss_depthnet_softmax_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "lss_camencode_v2_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp] + [_i] * 6 + [_vp, _vp, _vp]),
+    "lss_depth_fuse_softmax_fwd": (_i, [_vp] * 5 + [_i] * 6 + [_vp, _vp]),
     "lss_lift_splat_fwd": (_i, [_vp] * 3 + [_i] * 9 + [_vp, _i, _vp]),
     "lss_lift_splat_bwd": (_i, [_vp, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp, _vp]),
     "lss_segmented_sum": (_i, [_vp, _vp, _i, _i, _vp, _vp]),

@@ -19,12 +19,15 @@ constexpr int LDS_LD = PIX + 1; // padded row of the [n][pix] logits tile
 // Shared tail of both kernels: K-quarter partials -> LDS -> bias -> outputs.
 template <int NT>
 __device__ __forceinline__ void depthnet_epilogue(const f32x4 (&acc)[NT], float* lds,
-                                                  const float* __restrict__ bias, int bn, int pix0,
-                                                  int HW, int D, int C, float* __restrict__ depth,
+                                                  const float* __restrict__ bias_d,
+                                                  const float* __restrict__ bias_c, int feat_row0,
+                                                  bool softmax, int bn, int pix0, int HW, int D,
+                                                  int C, float* __restrict__ depth,
                                                   float* __restrict__ feat) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, j = lane >> 4;
-  const int NO = D + C;
+  // logit rows: depth bins at [0, D), context channels at [feat_row0, feat_row0 + C)
+  const int NO = feat_row0 + C;
   // partial[wave][n][pix] -> LDS
   float* part = lds;  // [4][NT*16][LDS_LD]
   const int NR = NT * 16;
@@ -42,14 +45,23 @@ __device__ __forceinline__ void depthnet_epilogue(const f32x4 (&acc)[NT], float*
     float v = part[o] + part[NR * LDS_LD + o];
     v += part[2 * NR * LDS_LD + o];
     v += part[3 * NR * LDS_LD + o];
-    logit[o] = v + bias[n];
+    if (n < D) v += bias_d[n];
+    else if (n >= feat_row0) v += bias_c[n - feat_row0];
+    logit[o] = v;
   }
   __syncthreads();
 
   // context features: feat[(bn*HW + pix)*C + c] = logit[D + c][pix]
   for (int e = tid; e < PIX * C; e += 256) {
     const int p = e / C, c = e % C;
-    if (pix0 + p < HW) feat[((size_t)bn * HW + pix0 + p) * C + c] = logit[(D + c) * LDS_LD + p];
+    if (pix0 + p < HW) feat[((size_t)bn * HW + pix0 + p) * C + c] = logit[(feat_row0 + c) * LDS_LD + p];
+  }
+  if (!softmax) {  // raw logits (a later kernel fuses them, ref MultiScaleDepthNet)
+    for (int e = tid; e < D * PIX; e += 256) {
+      const int d = e / PIX, p = e % PIX;
+      if (pix0 + p < HW) depth[((size_t)bn * D + d) * HW + pix0 + p] = logit[d * LDS_LD + p];
+    }
+    return;
   }
   // softmax over d for each of the 16 pixels: 16 lanes per pixel
   {
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(256) void depthnet_softmax_f32_kernel(
     }
   }
 
-  depthnet_epilogue<NT>(acc, lds, bias, bn, pix0, HW, D, C, depth, feat);
+  depthnet_epilogue<NT>(acc, lds, bias, bias + D, D, true, bn, pix0, HW, D, C, depth, feat);
 }
 
 // bf16 variant: x and W are rounded to bf16 in registers (inputs stay fp32 in
@@ -166,7 +178,133 @@ __global__ __launch_bounds__(256) void depthnet_softmax_bf16_kernel(
     }
   }
 
-  depthnet_epilogue<NT>(acc, lds, bias, bn, pix0, HW, D, C, depth, feat);
+  depthnet_epilogue<NT>(acc, lds, bias, bias + D, D, true, bn, pix0, HW, D, C, depth, feat);
+}
+
+// ---------------------------------------------------------------------------
+// Two-source variant for the vovnet models (ref: src/model_vovnet_transformer.py:73-122):
+// the depth logits come from a 1x1 conv over the depth head's hidden activations
+// (NHWC, fp32 or bf16, as the MFMA conv kernel leaves them) and the context features
+// from `feat_proj`, a 1x1 conv over the trunk's C3 map (NCHW fp32).  Same work split
+// and epilogue as above; depth tiles are rows [0, 16*NTD), context tiles follow.
+template <typename T>
+__device__ __forceinline__ f32x4 load_k4(const T* p);
+template <>
+__device__ __forceinline__ f32x4 load_k4<float>(const float* p) {
+  return *reinterpret_cast<const f32x4*>(p);
+}
+template <>
+__device__ __forceinline__ f32x4 load_k4<unsigned short>(const unsigned short* p) {
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return (f32x4){lss_bf2f((unsigned short)v[0]), lss_bf2f((unsigned short)v[1]),
+                 lss_bf2f((unsigned short)v[2]), lss_bf2f((unsigned short)v[3])};
+}
+
+template <int NTD, int NTC, typename T>
+__global__ __launch_bounds__(256) void camencode_v2_kernel(
+    const T* __restrict__ xd, const float* __restrict__ wd, const float* __restrict__ bd, int Cd,
+    const float* __restrict__ xf, const float* __restrict__ wf, const float* __restrict__ bf, int Cf,
+    int HW, int D, int C, int softmax, float* __restrict__ depth, float* __restrict__ feat) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, j = lane >> 4;
+  const int bn = blockIdx.y;
+  const int pix0 = blockIdx.x * PIX;
+  const int pix = min(pix0 + col, HW - 1);
+  constexpr int NT = NTD + NTC;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  {  // depth logits: B[k][pix] = xd[pixel row][k], one 4-channel load per lane and K block
+    const int kq = Cd >> 2;
+    const T* xb = xd + ((size_t)bn * HW + pix) * Cd + (size_t)wave * kq + 4 * j;
+    const float* wb = wd + (size_t)wave * kq + 4 * j;
+    for (int kb = 0; kb < kq; kb += 16) {
+      const f32x4 xs = load_k4<T>(xb + kb);
+#pragma unroll
+      for (int t = 0; t < NTD; ++t) {
+        const int n = 16 * t + col;
+        f32x4 wa = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (n < D) wa = *reinterpret_cast<const f32x4*>(wb + (size_t)n * Cd + kb);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], xs[s], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if (NTC > 0) {  // context features from the NCHW trunk map
+    const int kq = Cf >> 2;
+    const float* xb = xf + ((size_t)bn * Cf + (size_t)wave * kq) * HW + pix;
+    const float* wb = wf + (size_t)wave * kq + 4 * j;
+    for (int kb = 0; kb < kq; kb += 16) {
+      float xs[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xs[s] = xb[(size_t)(kb + 4 * j + s) * HW];
+#pragma unroll
+      for (int t = 0; t < NTC; ++t) {
+        const int n = 16 * t + col;
+        f32x4 wa = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (n < C) wa = *reinterpret_cast<const f32x4*>(wb + (size_t)n * Cf + kb);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          acc[NTD + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], xs[s], acc[NTD + t], 0, 0, 0);
+      }
+    }
+  }
+  depthnet_epilogue<NT>(acc, lds, bd, bf, 16 * NTD, softmax != 0, bn, pix0, HW, D, NTC > 0 ? C : 0,
+                        depth, feat);
+}
+
+// MultiScaleDepthNet tail (ref: src/model_vovnet_transformer.py:61-70): bilinear
+// (align_corners=False) upsample of the coarse logits, concat, 1x1 fusion conv,
+// eval-mode BatchNorm (folded into scale/shift), ReLU, softmax over D.
+// One wave per output pixel; lane d owns depth bin d (D <= 64).
+__global__ __launch_bounds__(256) void depth_fuse_softmax_kernel(
+    const float* __restrict__ d3, const float* __restrict__ d4, const float* __restrict__ w,
+    const float* __restrict__ scale, const float* __restrict__ shift, int BN, int D, int H, int W,
+    int H4, int W4, float rh, float rw, float* __restrict__ depth) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* wt = lds;                 // [2D][D + 1] transposed fusion weights
+  float* vec = lds + 2 * D * (D + 1);  // [4 waves][2D]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < D * 2 * D; e += 256) {
+    const int n = e / (2 * D), k = e % (2 * D);
+    wt[k * (D + 1) + n] = w[e];
+  }
+  const int HW = H * W;
+  const long long gp = (long long)blockIdx.x * 4 + wave;  // global pixel
+  const bool live = gp < (long long)BN * HW;
+  const int bn = live ? (int)(gp / HW) : 0, pix = live ? (int)(gp % HW) : 0;
+  const int oh = pix / W, ow = pix % W;
+  // source coordinates exactly as ATen's area_pixel_compute_source_index (align_corners=False)
+  float sh = rh * ((float)oh + 0.5f) - 0.5f;
+  float sw = rw * ((float)ow + 0.5f) - 0.5f;
+  sh = sh < 0.f ? 0.f : sh;
+  sw = sw < 0.f ? 0.f : sw;
+  const int h0 = (int)sh, w0 = (int)sw;
+  const int h1 = h0 + (h0 < H4 - 1 ? 1 : 0), w1 = w0 + (w0 < W4 - 1 ? 1 : 0);
+  const float lh1 = sh - (float)h0, lh0 = 1.f - lh1;
+  const float lw1 = sw - (float)w0, lw0 = 1.f - lw1;
+  if (lane < D) {
+    const float* c = d4 + ((size_t)bn * D + lane) * (H4 * W4);
+    const float up = lh0 * (lw0 * c[h0 * W4 + w0] + lw1 * c[h0 * W4 + w1]) +
+                     lh1 * (lw0 * c[h1 * W4 + w0] + lw1 * c[h1 * W4 + w1]);
+    vec[wave * 2 * D + lane] = d3[((size_t)bn * D + lane) * HW + pix];
+    vec[wave * 2 * D + D + lane] = up;
+  }
+  __syncthreads();
+  float v = -INFINITY;
+  if (lane < D) {
+    float a = 0.f;
+    const float* x = vec + wave * 2 * D;
+    for (int k = 0; k < 2 * D; ++k) a = fmaf(wt[k * (D + 1) + lane], x[k], a);
+    v = fmaxf(a * scale[lane] + shift[lane], 0.f);
+  }
+  const float mx = lss_wave_max(v);
+  const float e = lane < D ? expf(v - mx) : 0.f;
+  const float sum = lss_wave_sum(e);
+  if (live && lane < D) depth[((size_t)bn * D + lane) * HW + pix] = e / sum;
 }
 
 template <int NT>
@@ -205,4 +343,67 @@ extern "C" int lss_depthnet_softmax_fwd(const float* x, const float* w, const fl
     default: return LSS_E_SHAPE;  // D + C <= 192
   }
 #undef LSS_DN_CASE
+}
+
+template <int NTD, int NTC, typename T>
+static int launch_camencode_v2(const void* xd, const float* wd, const float* bd, int Cd,
+                               const float* xf, const float* wf, const float* bf, int Cf, int BN,
+                               int HW, int D, int C, int softmax, float* depth, float* feat,
+                               hipStream_t st) {
+  const size_t lds_bytes = (size_t)5 * (NTD + NTC) * 16 * LDS_LD * sizeof(float);
+  dim3 grid(lss_cdiv(HW, PIX), BN);
+  hipLaunchKernelGGL((camencode_v2_kernel<NTD, NTC, T>), grid, dim3(256), lds_bytes, st,
+                     static_cast<const T*>(xd), wd, bd, Cd, xf, wf, bf, Cf, HW, D, C, softmax, depth,
+                     feat);
+  return lss_launch_status();
+}
+
+extern "C" int lss_camencode_v2_fwd(const void* x_depth, int dt, const float* w_depth,
+                                    const float* b_depth, int Cd, const float* x_feat,
+                                    const float* w_feat, const float* b_feat, int Cf, int BN, int HW,
+                                    int D, int C, int softmax, float* depth, float* feat,
+                                    void* stream) {
+  LSS_CHECK_PTR(x_depth); LSS_CHECK_PTR(w_depth); LSS_CHECK_PTR(b_depth); LSS_CHECK_PTR(depth);
+  LSS_CHECK_POS(BN); LSS_CHECK_POS(HW); LSS_CHECK_POS(D); LSS_CHECK_POS(Cd);
+  if (dt != LSS_DT_F32 && dt != LSS_DT_BF16) return LSS_E_LAYOUT;
+  if (C < 0 || (C > 0 && (x_feat == nullptr || w_feat == nullptr || b_feat == nullptr || feat == nullptr)))
+    return C < 0 ? LSS_E_SHAPE : LSS_E_NULL;
+  if (Cd % 64 != 0 || (C > 0 && Cf % 64 != 0) || BN > 65535) return LSS_E_SHAPE;
+  if (((reinterpret_cast<uintptr_t>(w_depth) | reinterpret_cast<uintptr_t>(x_depth)) & 15) != 0)
+    return LSS_E_ALIGN;
+  if (C > 0 && (reinterpret_cast<uintptr_t>(w_feat) & 15) != 0) return LSS_E_ALIGN;
+  const int ntd = (D + 15) / 16, ntc = (C + 15) / 16;
+  hipStream_t st = lss_stream(stream);
+#define LSS_V2_CASE(a, b)                                                                         \
+  if (ntd == a && ntc == b)                                                                       \
+    return dt == LSS_DT_F32                                                                       \
+               ? launch_camencode_v2<a, b, float>(x_depth, w_depth, b_depth, Cd, x_feat, w_feat,  \
+                                                  b_feat, Cf, BN, HW, D, C, softmax, depth, feat, st) \
+               : launch_camencode_v2<a, b, unsigned short>(x_depth, w_depth, b_depth, Cd, x_feat, \
+                                                           w_feat, b_feat, Cf, BN, HW, D, C,      \
+                                                           softmax, depth, feat, st);
+  LSS_V2_CASE(3, 0) LSS_V2_CASE(3, 4) LSS_V2_CASE(3, 8)
+  LSS_V2_CASE(4, 0) LSS_V2_CASE(4, 4) LSS_V2_CASE(4, 8)
+  LSS_V2_CASE(1, 0) LSS_V2_CASE(1, 1)
+#undef LSS_V2_CASE
+  return LSS_E_SHAPE;  // D in (0,16] u (32,64], C in {0, (48,64], (112,128]} (+ the unit-test shape)
+}
+
+extern "C" int lss_depth_fuse_softmax_fwd(const float* d3, const float* d4, const float* w_fusion,
+                                          const float* scale, const float* shift, int BN, int D,
+                                          int H, int W, int H4, int W4, float* depth, void* stream) {
+  LSS_CHECK_PTR(d3); LSS_CHECK_PTR(d4); LSS_CHECK_PTR(w_fusion); LSS_CHECK_PTR(scale);
+  LSS_CHECK_PTR(shift); LSS_CHECK_PTR(depth);
+  LSS_CHECK_POS(BN); LSS_CHECK_POS(D); LSS_CHECK_POS(H); LSS_CHECK_POS(W); LSS_CHECK_POS(H4);
+  LSS_CHECK_POS(W4);
+  if (D > 64) return LSS_E_SHAPE;
+  const long long npix = (long long)BN * H * W;
+  if (npix >= (1LL << 31)) return LSS_E_SHAPE;
+  const size_t lds_bytes = ((size_t)2 * D * (D + 1) + 4 * 2 * D) * sizeof(float);
+  // ATen: scale = (float)in / out for align_corners=False with an explicit output size
+  const float rh = (float)H4 / (float)H, rw = (float)W4 / (float)W;
+  hipLaunchKernelGGL(depth_fuse_softmax_kernel, dim3(lss_cdiv(npix, 4)), dim3(256), lds_bytes,
+                     lss_stream(stream), d3, d4, w_fusion, scale, shift, BN, D, H, W, H4, W4, rh, rw,
+                     depth);
+  return lss_launch_status();
 }

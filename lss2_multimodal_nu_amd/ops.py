@@ -203,6 +203,61 @@ def depthnet_softmax(x, weight, bias, D, C, math=DT_F32):
     return depth, feat
 
 
+def camencode_v2(hidden, w_depth, b_depth, D, c3=None, w_feat=None, b_feat=None, softmax=True):
+    """K2v.  hidden (BN,fH,fW,Cd) NHWC fp32|bf16; w_depth (D,Cd[,1,1]); optional c3
+    (BN,Cf,fH,fW) fp32 NCHW with w_feat (C,Cf[,1,1]) / b_feat.  Returns depth
+    (BN,D,fH,fW) (probabilities, or raw logits with softmax=False) and feat
+    (BN,fH,fW,C) or None."""
+    BN, fH, fW, Cd = hidden.shape
+    if not hidden.is_contiguous() or hidden.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("hidden must be contiguous NHWC fp32/bf16")
+    dt = DT_F32 if hidden.dtype == torch.float32 else DT_BF16
+    wd = w_depth.reshape(w_depth.shape[0], -1)
+    _f32c(wd, "w_depth", (D, Cd))
+    _f32c(b_depth, "b_depth", (D,))
+    dev = hidden.device
+    depth = torch.empty(BN, D, fH, fW, dtype=torch.float32, device=dev)
+    if c3 is not None:
+        _f32c(c3, "c3")
+        if c3.shape[0] != BN or tuple(c3.shape[2:]) != (fH, fW):
+            raise ValueError("c3 %s does not match hidden %s" % (tuple(c3.shape), tuple(hidden.shape)))
+        Cf = c3.shape[1]
+        wf = w_feat.reshape(w_feat.shape[0], -1)
+        C = wf.shape[0]
+        _f32c(wf, "w_feat", (C, Cf))
+        _f32c(b_feat, "b_feat", (C,))
+        feat = torch.empty(BN, fH, fW, C, dtype=torch.float32, device=dev)
+        args = (N.ptr(c3), N.ptr(wf), N.ptr(b_feat), Cf)
+    else:
+        C, feat, args = 0, None, (None, None, None, 0)
+    with _timed("camencode_v2"):
+        N.check(N.lib().lss_camencode_v2_fwd(N.ptr(hidden), dt, N.ptr(wd), N.ptr(b_depth), Cd, *args, BN,
+                                             fH * fW, D, C, 1 if softmax else 0, N.ptr(depth),
+                                             N.ptr(feat) if feat is not None else None, N.stream()),
+                "lss_camencode_v2_fwd")
+    return depth, feat
+
+
+def depth_fuse_softmax(d3, d4, w_fusion, scale, shift):
+    """MultiScaleDepthNet tail: d3 (BN,D,H,W), d4 (BN,D,H4,W4) raw logits ->
+    softmax(relu(scale * fusion([d3, up(d4)]) + shift)) (BN,D,H,W)."""
+    BN, D, H, W = d3.shape
+    _f32c(d3, "d3")
+    _f32c(d4, "d4")
+    if d4.shape[0] != BN or d4.shape[1] != D:
+        raise ValueError("d4 %s does not match d3 %s" % (tuple(d4.shape), tuple(d3.shape)))
+    w2 = w_fusion.reshape(w_fusion.shape[0], -1)
+    _f32c(w2, "w_fusion", (D, 2 * D))
+    _f32c(scale, "scale", (D,))
+    _f32c(shift, "shift", (D,))
+    depth = torch.empty_like(d3)
+    with _timed("depth_fuse_softmax"):
+        N.check(N.lib().lss_depth_fuse_softmax_fwd(N.ptr(d3), N.ptr(d4), N.ptr(w2), N.ptr(scale), N.ptr(shift),
+                                                   BN, D, H, W, d4.shape[2], d4.shape[3], N.ptr(depth),
+                                                   N.stream()), "lss_depth_fuse_softmax_fwd")
+    return depth
+
+
 def lift_splat_fwd(feat, ws, dims, nx, layout=BEV_NCHW_F32, tag="lift_splat_fwd"):
     """K5/K6 on a bucketed workspace (depth weights already sit in ws.entries).
     dims = (B,N,D,fH,fW,C).  Returns the BEV tensor with LOGICAL shape
