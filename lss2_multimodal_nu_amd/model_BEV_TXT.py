@@ -96,7 +96,8 @@ class _VoxelPoolFn(torch.autograd.Function):
 class _LiftSplatMixin:
     """Everything `LSS` and `BEV_TXT` share on the camera->BEV path."""
 
-    def _init_lift_splat(self, bsize, grid_conf, data_aug_conf, outC, encoder, precision):
+    def _init_grid(self, bsize, grid_conf, data_aug_conf):
+        """Grid Parameters, frustum and the host-side caches of the index path."""
         self.grid_conf = grid_conf
         self.data_aug_conf = data_aug_conf
         self.bsize = bsize
@@ -105,18 +106,21 @@ class _LiftSplatMixin:
         self.bx = nn.Parameter(bx, requires_grad=False)
         self.nx = nn.Parameter(nx, requires_grad=False)
         self.downsample = 16
-        self.camC = 64
         self.frustum = self.create_frustum()
-        self.D = self.frustum.shape[0]
-        self.encoder = encoder if encoder is not None else TrunkFeatures()
-        self.camencode = CamEncode(self.D, self.camC, self.downsample)
-        self.bevencode = BevEncode(inC=self.camC, outC=outC, precision=precision)
-        self.precision = precision
         self.use_quickcumsum = True  # kept for API compatibility; both settings take the HIP path
         self._nx_cache = None
         self._ws = {}
         self._stage = None
         self._stage_i = 0
+
+    def _init_lift_splat(self, bsize, grid_conf, data_aug_conf, outC, encoder, precision):
+        self._init_grid(bsize, grid_conf, data_aug_conf)
+        self.camC = 64
+        self.D = self.frustum.shape[0]
+        self.encoder = encoder if encoder is not None else TrunkFeatures()
+        self.camencode = CamEncode(self.D, self.camC, self.downsample)
+        self.bevencode = BevEncode(inC=self.camC, outC=outC, precision=precision)
+        self.precision = precision
 
     # -- grid bookkeeping ---------------------------------------------------
     def create_frustum(self):

@@ -43,8 +43,9 @@ class _FoldedConv:
     """Packed weights + eval-mode BatchNorm folded into (scale, shift) for one
     conv of the HIP path; rebuilt only when a source tensor changes."""
 
-    def __init__(self, conv, bn=None):
+    def __init__(self, conv, bn=None, pack=True):
         self.conv, self.bn = conv, bn
+        self.pack = pack  # False: only the folded (scale, shift) are wanted
         self.key = None
         self.w = self.scale = self.shift = None
 
@@ -72,12 +73,19 @@ class _FoldedConv:
             with torch.no_grad():
                 w32 = self.conv.weight.detach().float().contiguous()
                 # (the 1x1/2 conv reads parity phase (0,0) only: plain pack)
-                self.w = ops.pack_conv_weight_s2d(w32, self.conv.padding[0]) \
-                    if (self._s2d(dt) and self.conv.kernel_size[0] > 1) else ops.pack_conv_weight(w32, dt)
+                if not self.pack:
+                    self.w = None
+                elif self._s2d(dt) and self.conv.kernel_size[0] > 1:
+                    self.w = ops.pack_conv_weight_s2d(w32, self.conv.padding[0])
+                else:
+                    self.w = ops.pack_conv_weight(w32, dt)
                 if self.bn is not None:
                     inv = torch.rsqrt(self.bn.running_var.float() + self.bn.eps)
                     self.scale = (self.bn.weight.float() * inv).contiguous()
-                    self.shift = (self.bn.bias.float() - self.bn.running_mean.float() * self.scale).contiguous()
+                    mean = self.bn.running_mean.float()
+                    if self.conv.bias is not None:  # conv bias in front of the BN (vovnet heads)
+                        mean = mean - self.conv.bias.detach().float()
+                    self.shift = (self.bn.bias.float() - mean * self.scale).contiguous()
                 else:
                     self.scale = None
                     self.shift = self.conv.bias.detach().float().contiguous() if self.conv.bias is not None else None

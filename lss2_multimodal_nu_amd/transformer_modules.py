@@ -1,0 +1,141 @@
+"""Host-side mirror of the reference's `src/transformer_modules.py`: sine position
+encoding (:12-59), single-scale deformable attention (:62-161), the encoder layer
+(:164-207) and `LightweightBEVTransformer` (:210-258).
+
+Constructor arguments, `forward()` signatures and `state_dict` keys follow the
+reference.  torch.nn modules are PARAMETER CONTAINERS: in inference the
+arithmetic runs in csrc/ (token-major NHWC activations: the linears are 1x1
+MFMA convs, sampling + softmax + weighting is one gather kernel, residual +
+LayerNorm one row kernel).  Training / autograd runs the same parameters through
+torch ops with all heads sampled in ONE batched `grid_sample`.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+
+class PositionEmbeddingSine(nn.Module):
+    """(B, C, H, W) -> (B, 2*num_pos_feats, H, W): first half encodes the row, second
+    half the column; channel 2i = sin, 2i+1 = cos of coord / T^(2i/npf)."""
+
+    def __init__(self, num_pos_feats=128, temperature=10000, normalize=True, scale=None):
+        super().__init__()
+        if scale is not None and normalize is False:
+            raise ValueError("normalize should be True if scale is passed")
+        self.num_pos_feats = num_pos_feats
+        self.temperature = temperature
+        self.normalize = normalize
+        self.scale = 2 * math.pi if scale is None else scale
+
+    def table(self, H, W, device):
+        """(H*W, 2*npf) token-major table (the same numbers for every sample)."""
+        npf = self.num_pos_feats
+        ys = torch.arange(H, dtype=torch.float32, device=device)
+        xs = torch.arange(W, dtype=torch.float32, device=device)
+        if self.normalize:
+            ys = ys / (H - 1) * self.scale
+            xs = xs / (W - 1) * self.scale
+        k = torch.arange(npf, dtype=torch.float32, device=device)
+        dim_t = self.temperature ** (2 * torch.div(k, 2, rounding_mode="floor") / npf)
+        even = (torch.arange(npf, device=device) % 2) == 0
+        ang_x, ang_y = xs[:, None] / dim_t, ys[:, None] / dim_t
+        px = torch.where(even, ang_x.sin(), ang_x.cos())
+        py = torch.where(even, ang_y.sin(), ang_y.cos())
+        return torch.cat([py[:, None, :].expand(H, W, npf), px[None, :, :].expand(H, W, npf)], 2).reshape(H * W, 2 * npf)
+
+    def forward(self, x):
+        B, _, H, W = x.shape
+        t = self.table(H, W, x.device)
+        return t.t().reshape(1, -1, H, W).expand(B, -1, -1, -1)
+
+
+class DeformableAttention(nn.Module):
+    """Every query token samples `n_points` bilinear taps per head around its own
+    grid position and mixes them with softmax weights; offsets and weights are
+    linear in the query."""
+
+    def __init__(self, d_model=256, n_heads=8, n_points=8):
+        super().__init__()
+        self.d_model, self.n_heads, self.n_points = d_model, n_heads, n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        """Zero offset/attention weights; offset bias = head h looks along direction
+        2*pi*h/heads (scaled to the unit square's edge), point p at distance p+1."""
+        with torch.no_grad():
+            self.sampling_offsets.weight.zero_()
+            ang = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+            d = torch.stack([ang.cos(), ang.sin()], -1)
+            d = d / d.abs().max(-1, keepdim=True)[0]
+            steps = torch.arange(1, self.n_points + 1, dtype=torch.float32)
+            self.sampling_offsets.bias.copy_((d[:, None, :] * steps[None, :, None]).reshape(-1))
+            self.attention_weights.weight.zero_()
+            self.attention_weights.bias.zero_()
+            nn.init.xavier_uniform_(self.value_proj.weight)
+            self.value_proj.bias.zero_()
+            nn.init.xavier_uniform_(self.output_proj.weight)
+            self.output_proj.bias.zero_()
+
+    def forward(self, query, value, reference_points):
+        """query, value (B, N, C) with N = H*H; reference_points (B, N, 2) in [0,1] -> (B, N, C)."""
+        B, N, C = query.shape
+        H = W = int(math.sqrt(N))
+        nh, npt, ch = self.n_heads, self.n_points, C // self.n_heads
+        off = self.sampling_offsets(query).view(B, N, nh, npt, 2)
+        aw = self.attention_weights(query).view(B, N, nh, npt).softmax(-1)
+        loc = (reference_points[:, :, None, None, :] + off / H).clamp(0, 1)
+        v = self.value_proj(value).view(B, H, W, nh, ch).permute(0, 3, 4, 1, 2).reshape(B * nh, ch, H, W)
+        grid = (loc * 2.0 - 1.0).permute(0, 2, 1, 3, 4).reshape(B * nh, N, npt, 2)
+        s = F.grid_sample(v, grid, mode="bilinear", align_corners=False)  # (B*nh, ch, N, npt)
+        w = aw.permute(0, 2, 1, 3).reshape(B * nh, 1, N, npt)
+        out = (s * w).sum(-1).view(B, nh, ch, N).permute(0, 3, 1, 2).reshape(B, N, C)
+        return self.output_proj(out)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, n_heads=8, dim_feedforward=1024, dropout=0.1):
+        super().__init__()
+        self.self_attn = DeformableAttention(d_model, n_heads, n_points=8)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.activation = nn.GELU()
+
+    def forward(self, src, pos, reference_points):
+        """src (B, N, C); pos (B, C, H, W); reference_points (B, N, 2)."""
+        q = src + pos.flatten(2).permute(0, 2, 1)
+        src = self.norm1(src + self.dropout1(self.self_attn(q, src, reference_points)))
+        ff = self.linear2(self.dropout(self.activation(self.linear1(src))))
+        return self.norm2(src + self.dropout2(ff))
+
+
+class LightweightBEVTransformer(nn.Module):
+    def __init__(self, d_model=256, n_heads=8, dim_feedforward=1024, dropout=0.1):
+        super().__init__()
+        self.d_model = d_model
+        self.pos_encoder = PositionEmbeddingSine(d_model // 2, normalize=True)
+        self.encoder = TransformerEncoderLayer(d_model, n_heads, dim_feedforward, dropout)
+
+    @staticmethod
+    def reference_points(H, W, device):
+        gy, gx = torch.meshgrid(torch.linspace(0, 1, H, device=device), torch.linspace(0, 1, W, device=device),
+                                indexing="ij")
+        return torch.stack([gx, gy], -1).view(1, H * W, 2)
+
+    def forward(self, x):
+        """(B, C, H, W) -> (B, C, H, W)."""
+        B, C, H, W = x.shape
+        pos = self.pos_encoder(x)
+        ref = self.reference_points(H, W, x.device).expand(B, -1, -1)
+        y = self.encoder(x.flatten(2).permute(0, 2, 1), pos, ref)
+        return y.permute(0, 2, 1).reshape(B, C, H, W)
