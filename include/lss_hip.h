@@ -51,6 +51,13 @@ extern "C" {
 #define LSS_DT_F32 0
 #define LSS_DT_BF16 1
 
+/* `relu` argument of the conv entry points: activation code, optionally OR-ed with
+ * LSS_OUT_F32 (lss_conv2d_fwd only: y is written as fp32 although dt is bf16) */
+#define LSS_ACT_NONE 0
+#define LSS_ACT_RELU 1
+#define LSS_ACT_GELU 2 /* 0.5 x (1 + erf(x / sqrt 2)), torch.nn.GELU() */
+#define LSS_OUT_F32 16
+
 int lss_abi_version(void);
 /* Static string for a return code of this library (never NULL). */
 const char* lss_error_string(int code);
@@ -189,6 +196,35 @@ int lss_lift_splat_bwd(const void* grad_bev, int layout, const int32_t* voxel,
  */
 int lss_segmented_sum(const float* x, const int32_t* seg_start, int M, int C, float* y,
                       void* stream);
+
+/* ---------------------------------------------------------------------------
+ * BEV transformer, token-major (B, H*W, 256) rows = NHWC activations.
+ * The linear layers are 1x1 convs (lss_conv2d_fwd); these three kernels are the
+ * rest of the encoder layer.  C must be 256, n_heads = n_points = 8 (the
+ * reference's only configuration).
+ */
+/* q = x + pos.  replaces: src/transformer_modules.py:199-200 (pos_flat, q = src + pos)
+ *   x, q (B, T, C) in `dt`; pos (T, C) fp32 = PositionEmbeddingSine table (:25-59) */
+int lss_add_pos_fwd(const void* x, const float* pos, int B, int T, int C, int dt, void* q,
+                    void* stream);
+
+/* Deformable attention core.  replaces: src/transformer_modules.py:117-156 (views,
+ *  softmax over points, sampling locations, the per-head grid_sample loop, weighting).
+ *   value          (B, H, W, C) in `dt` = value_proj(src)
+ *   offsets_logits (B*H*W, 192) fp32: [0,128) = sampling_offsets(q) as (head, point, xy),
+ *                  [128,192) = attention_weights(q) as (head, point)
+ *   ref_x (W), ref_y (H) fp32 = torch.linspace(0, 1, n)  (:243-244)
+ *   out            (B, H*W, C) in `dt`, ready for output_proj
+ * Sampling is bilinear with zero padding at align_corners=False pixel coordinates, both
+ * offset axes divided by H as the reference does (:124). */
+int lss_deform_attn_fwd(const void* value, const float* offsets_logits, const float* ref_x,
+                        const float* ref_y, int B, int H, int W, int n_heads, int n_points, int C,
+                        int dt, void* out, void* stream);
+
+/* nn.LayerNorm(C) over rows.  replaces: src/transformer_modules.py:204,208 (norm1, norm2)
+ *   x (rows, C) in x_dt; y (rows, C) in y_dt; gamma, beta (C) fp32 */
+int lss_layernorm_fwd(const void* x, int x_dt, const float* gamma, const float* beta,
+                      long long rows, int C, float eps, void* y, int y_dt, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K8  BevEncode convolutions: implicit-GEMM on MFMA, NHWC activations.

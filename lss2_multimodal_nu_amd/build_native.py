@@ -24,6 +24,7 @@ SOURCES = {
     "splat.hip": [],
     "conv_mfma.hip": [],
     "layout.hip": [],
+    "bev_transformer.hip": [],
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-variable",
           "-Wno-unused-but-set-variable"]

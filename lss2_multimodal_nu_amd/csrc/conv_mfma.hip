@@ -37,7 +37,8 @@ struct ConvArgs {
   int Cin;       // C2 + Cx
   int Cout, KH, KW, stride, pad;
   int Ho, Wo, M;
-  int relu;
+  int relu;     // activation: 0 none, 1 ReLU, 2 GELU (erf form)
+  int out_f32;  // bf16 kernels: write y as fp32
   float ry, rx;  // (H-1)/(Hin-1), (W-1)/(Win-1) for the align_corners upsample
   // optional fused 1x1 head (ref: src/modules.py:115 up2[4]): out[b,k,oy,ox] =
   // head_b[k] + sum_co act(...)[co] * head_w[k, co]; NCHW fp32; needs Cout == BN
@@ -46,6 +47,12 @@ struct ConvArgs {
   float* head_out;
   int head_n;
 };
+
+__device__ __forceinline__ float conv_act(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+  return v;
+}
 
 template <typename T>
 struct Frag;
@@ -248,8 +255,8 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
         const size_t o = (size_t)mm * a.Cout + co;
         if (res) v += (sizeof(T) == 2) ? lss_bf2f(reinterpret_cast<const unsigned short*>(res)[o])
                                        : reinterpret_cast<const float*>(res)[o];
-        if (a.relu) v = fmaxf(v, 0.f);
-        if (sizeof(T) == 2) reinterpret_cast<unsigned short*>(y)[o] = lss_f2bf(v);
+        v = conv_act(v, a.relu);
+        if (sizeof(T) == 2 && !a.out_f32) reinterpret_cast<unsigned short*>(y)[o] = lss_f2bf(v);
         else reinterpret_cast<float*>(y)[o] = v;
       }
     }
@@ -668,20 +675,30 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
           v[2 * k + 1] += lss_bf2f((unsigned short)(ru[k] >> 16));
         }
       }
-      if (a.relu) {
+      if (a.relu == 1) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+      } else if (a.relu == 2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = conv_act(v[k], 2);
       }
-      uint4 ov;
-      ov.x = lss_pack_bf2(v[0], v[1]); ov.y = lss_pack_bf2(v[2], v[3]);
-      ov.z = lss_pack_bf2(v[4], v[5]); ov.w = lss_pack_bf2(v[6], v[7]);
-      *reinterpret_cast<uint4*>(y + o) = ov;
+      if (a.out_f32) {
+        float* yf = reinterpret_cast<float*>(a.y) + o;
+        *reinterpret_cast<f32x4*>(yf) = (f32x4){v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(yf + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+      } else {
+        uint4 ov;
+        ov.x = lss_pack_bf2(v[0], v[1]); ov.y = lss_pack_bf2(v[2], v[3]);
+        ov.z = lss_pack_bf2(v[4], v[5]); ov.w = lss_pack_bf2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(y + o) = ov;
+      }
     } else {
       for (int k = 0; k < 8 && co + k < a.Cout; ++k) {
         float t = v[k];
         if (res) t += lss_bf2f(res[o + k]);
-        if (a.relu) t = fmaxf(t, 0.f);
-        y[o + k] = lss_f2bf(t);
+        t = conv_act(t, a.relu);
+        if (a.out_f32) reinterpret_cast<float*>(a.y)[o + k] = t;
+        else y[o + k] = lss_f2bf(t);
       }
     }
   }
@@ -823,7 +840,9 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   const long long M = (long long)B * a.Ho * a.Wo;
   if (M >= (1LL << 31)) return LSS_E_SHAPE;
   a.M = (int)M;
-  a.relu = relu;
+  a.relu = relu & 3;
+  a.out_f32 = (relu & LSS_OUT_F32) != 0;
+  if (a.relu == 3 || (relu & ~(3 | LSS_OUT_F32)) != 0) return LSS_E_LAYOUT;
   a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0;
   a.ry = a.Hin > 1 ? (float)(H - 1) / (float)(a.Hin - 1) : 0.f;
   a.rx = a.Win > 1 ? (float)(W - 1) / (float)(a.Win - 1) : 0.f;
@@ -835,6 +854,12 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
       getenv("LSS_CONV_DIRECT") == nullptr) {
     if (fused) launch_conv_lds<1, 3, 3, 1>(a, st);
     else launch_conv_lds<0, 3, 3, 1>(a, st);
+    return lss_launch_status();
+  }
+  // 1x1 / stride 1: the token-major linear layers of the BEV transformer and the 1x1 convs
+  if (dt == LSS_DT_BF16 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && !fused && a.Cin % 64 == 0 &&
+      getenv("LSS_CONV_DIRECT") == nullptr) {
+    launch_conv_lds<0, 1, 1, 0>(a, st);
     return lss_launch_status();
   }
   if (dt == LSS_DT_BF16) {
@@ -871,7 +896,8 @@ extern "C" int lss_conv2d_s2_fwd(const void* x, const void* w_s2d, const float* 
   const long long M = (long long)B * a.Ho * a.Wo;
   if (M >= (1LL << 31)) return LSS_E_SHAPE;
   a.M = (int)M;
-  a.relu = relu;
+  a.relu = relu & 3;
+  a.out_f32 = 0;
   a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0;
   a.ry = a.rx = 0.f;
   hipStream_t st = lss_stream(stream);
@@ -905,7 +931,8 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
   const long long M = (long long)B * a.Ho * a.Wo;
   if (M >= (1LL << 31)) return LSS_E_SHAPE;
   a.M = (int)M;
-  a.relu = relu;
+  a.relu = relu & 3;
+  a.out_f32 = 0;
   a.head_w = head_w; a.head_b = head_b; a.head_out = out; a.head_n = head_n;
   a.ry = a.Hin > 1 ? (float)(H - 1) / (float)(a.Hin - 1) : 0.f;
   a.rx = a.Win > 1 ? (float)(W - 1) / (float)(a.Win - 1) : 0.f;

@@ -134,17 +134,35 @@ class BEVEncoderTransformer(nn.Module):
     def __init__(self, in_channels, out_channels=4, precision=None):
         super().__init__()
         self.compress = nn.Sequential(nn.Conv2d(in_channels, 256, 1), nn.BatchNorm2d(256), nn.ReLU(inplace=True))
-        self.transformer = LightweightBEVTransformer(d_model=256, n_heads=8, dim_feedforward=1024, dropout=0.1)
+        self.transformer = LightweightBEVTransformer(d_model=256, n_heads=8, dim_feedforward=1024, dropout=0.1,
+                                                     precision=precision)
         self.seg_head = nn.Sequential(
             nn.Conv2d(256, 128, 3, padding=1), nn.BatchNorm2d(128), nn.ReLU(inplace=True),
             nn.Conv2d(128, 64, 3, padding=1), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
             nn.Conv2d(64, out_channels, 1))
         self.precision = precision
+        self._fc = _FoldedConv(self.compress[0], self.compress[1])
+        self._fs0 = _FoldedConv(self.seg_head[0], self.seg_head[1])
+        self._fs1 = _FoldedConv(self.seg_head[3], self.seg_head[4])
+        self._fs2 = _FoldedConv(self.seg_head[6])
+
+    def forward_nhwc(self, x, dt):
+        """HIP path.  x (B,H,W,C_in) NHWC in dt -> seg (B,out_C,H,W) fp32 NCHW, refined (B,H,W,256) NHWC in dt."""
+        h = self._fc.run(x, dt, relu=True)
+        refined = self.transformer.forward_nhwc(h, dt)
+        s = self._fs1.run(self._fs0.run(refined, dt, relu=True), dt, relu=True)
+        w, _, shift = self._fs2.get(dt)
+        seg = ops.conv2d_nhwc(s, w, (1, 1), 1, 0, None, shift, None, False, dt=dt, out_f32=True)
+        return seg.permute(0, 3, 1, 2).contiguous(), refined
 
     def forward(self, x):
         """(B, C_in, H, W) -> seg (B, out_C, H, W), refined (B, 256, H, W)."""
-        refined = self.transformer(self.compress(x))
-        return self.seg_head(refined), refined
+        if _needs_autograd(self, x):
+            refined = self.transformer(self.compress(x))
+            return self.seg_head(refined), refined
+        dt = _dt(self.precision)
+        seg, refined = self.forward_nhwc(_to_nhwc(x, dt), dt)
+        return seg, ops.nhwc_to_nchw(refined, dt)
 
 
 # ----------------------------------------------------------------------------
@@ -196,7 +214,8 @@ class BEVCameraFusion(nn.Module):
         self.norm = nn.LayerNorm(camera_dim)
 
     def forward(self, camera_feat, bev_feat):
-        tok = bev_feat.mean(dim=(2, 3)).unsqueeze(1)  # adaptive_avg_pool2d(., 1)
+        """bev_feat: (B, C, H, W) map, or its global average (B, C) if the caller already pooled it."""
+        tok = (bev_feat.mean(dim=(2, 3)) if bev_feat.dim() == 4 else bev_feat).unsqueeze(1)
         return self.norm(camera_feat + self.cross_attn(camera_feat, tok, tok)[0])
 
 
@@ -301,15 +320,23 @@ class VoVNetBEVTransformer(_LiftSplatMixin, nn.Module):
         c3, c4 = feats["c3"], feats["c4"]
         N = c3.shape[0] // B
 
-        bev_feats = self.get_voxels(c3, c4, rots, trans, intrins, post_rots, post_trans)
-        bev_seg, bev_refined = self.bev_encoder(bev_feats)
+        be = self.bev_encoder
+        if _needs_autograd(be, c3, c4) or _needs_autograd(self.depth_net) or _needs_autograd(self.cam_encode):
+            bev_seg, bev_refined = be(self.get_voxels(c3, c4, rots, trans, intrins, post_rots, post_trans))
+            bev_pooled = bev_refined.mean(dim=(2, 3))
+        else:  # the BEV grid goes to the encoder channels-last in the conv dtype: no NCHW fp32 round trip
+            dt = _dt(be.precision)
+            layout = ops.BEV_NHWC_BF16 if dt == ops.DT_BF16 else ops.BEV_NHWC_F32
+            grid = self.get_voxels(c3, c4, rots, trans, intrins, post_rots, post_trans, layout)
+            bev_seg, refined = be.forward_nhwc(grid.permute(0, 2, 3, 1), dt)
+            bev_pooled = refined.float().mean(dim=(1, 2))
 
         scene = self.sceneunder(self.feature_pyramid(c3))
         tokens = scene.mean(dim=(2, 3)).view(B, N, -1)
         if self.camera_transformer is not None:
             tokens = self.camera_transformer(tokens, self.camera_ids.unsqueeze(0).expand(B, -1))
         if self.bev_fusion is not None:
-            tokens = self.bev_fusion(tokens, bev_refined)
+            tokens = self.bev_fusion(tokens, bev_pooled)
         action, description = self.unified_predictor(tokens)
         return bev_seg, action, description
 

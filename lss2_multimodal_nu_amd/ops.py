@@ -7,7 +7,8 @@ torch's current HIP stream.  No CPU / eager fallbacks exist here.
 import torch
 
 from . import _native as N
-from ._native import BEV_NCHW_F32, BEV_NHWC_BF16, BEV_NHWC_F32, DT_BF16, DT_F32  # noqa: F401
+from ._native import (ACT_GELU, ACT_NONE, ACT_RELU, BEV_NCHW_F32, BEV_NHWC_BF16, BEV_NHWC_F32, DT_BF16,  # noqa: F401
+                      DT_F32, OUT_F32)
 
 
 def _f32c(t, name, shape=None):
@@ -352,6 +353,53 @@ def segmented_sum(x, seg_start):
 _TORCH_DT = {DT_F32: torch.float32, DT_BF16: torch.bfloat16}
 
 
+def add_pos(x, pos):
+    """q = x + pos: x (B, ..., 256) token rows in fp32|bf16, pos (T, 256) fp32 with T = tokens per sample."""
+    if not x.is_contiguous() or x.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("x must be contiguous fp32/bf16")
+    _f32c(pos, "pos")
+    B, C = x.shape[0], x.shape[-1]
+    T = x.numel() // (B * C)
+    if tuple(pos.shape) != (T, C):
+        raise ValueError("pos %s does not match %d tokens x %d channels" % (tuple(pos.shape), T, C))
+    q = torch.empty_like(x)
+    with _timed("add_pos"):
+        N.check(N.lib().lss_add_pos_fwd(N.ptr(x), N.ptr(pos), B, T, C, DT_F32 if x.dtype == torch.float32 else DT_BF16,
+                                        N.ptr(q), N.stream()), "lss_add_pos_fwd")
+    return q
+
+
+def deform_attn(value, offsets_logits, ref_x, ref_y, n_heads=8, n_points=8):
+    """value (B,H,W,256) fp32|bf16; offsets_logits (B,H,W,192) fp32 -> (B,H,W,256) in value's dtype."""
+    B, H, W, C = value.shape
+    if not value.is_contiguous() or value.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("value must be contiguous fp32/bf16 NHWC")
+    _f32c(offsets_logits, "offsets_logits", (B, H, W, n_heads * n_points * 3))
+    _f32c(ref_x, "ref_x", (W,))
+    _f32c(ref_y, "ref_y", (H,))
+    out = torch.empty_like(value)
+    with _timed("deform_attn"):
+        N.check(N.lib().lss_deform_attn_fwd(N.ptr(value), N.ptr(offsets_logits), N.ptr(ref_x), N.ptr(ref_y), B, H, W,
+                                            n_heads, n_points, C, DT_F32 if value.dtype == torch.float32 else DT_BF16,
+                                            N.ptr(out), N.stream()), "lss_deform_attn_fwd")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, out_dtype):
+    """nn.LayerNorm over the last (256-wide) dim of contiguous fp32|bf16 rows."""
+    if not x.is_contiguous() or x.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("x must be contiguous fp32/bf16")
+    C = x.shape[-1]
+    _f32c(gamma, "gamma", (C,))
+    _f32c(beta, "beta", (C,))
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    code = {torch.float32: DT_F32, torch.bfloat16: DT_BF16}
+    with _timed("layernorm"):
+        N.check(N.lib().lss_layernorm_fwd(N.ptr(x), code[x.dtype], N.ptr(gamma), N.ptr(beta), x.numel() // C, C,
+                                          float(eps), N.ptr(y), code[out_dtype], N.stream()), "lss_layernorm_fwd")
+    return y
+
+
 def pack_conv_weight(w_oihw, dt):
     """OIHW fp32 -> the conv kernels' [tap][Cout][Cin] layout in `dt`."""
     Cout, Cin, KH, KW = w_oihw.shape
@@ -365,10 +413,12 @@ def pack_conv_weight(w_oihw, dt):
 
 
 def conv2d_nhwc(x, w_packed, ksize, stride, pad, scale=None, shift=None, residual=None, relu=False,
-                x2=None, up=1, stats=None, dt=DT_BF16, tag="conv2d_fwd"):
+                x2=None, up=1, stats=None, dt=DT_BF16, tag="conv2d_fwd", out_f32=False):
     """K8.  x (B,H,W,Cx) NHWC in `dt`; x2 (B,H*up,W*up,C2) optional skip tensor
-    (conv input = cat([x2, upsample(x, up)])).  Returns y (B,Ho,Wo,Cout) in `dt`."""
+    (conv input = cat([x2, upsample(x, up)])).  Returns y (B,Ho,Wo,Cout) in `dt`
+    (fp32 with out_f32).  relu: False/True or an ACT_* code (ACT_GELU = erf GELU)."""
     tdt = _TORCH_DT[dt]
+    act = int(relu) | (OUT_F32 if (out_f32 and dt == DT_BF16) else 0)
     B, H, W, Cx = x.shape
     KH, KW = ksize
     taps, Cout, Cin = w_packed.shape
@@ -383,11 +433,11 @@ def conv2d_nhwc(x, w_packed, ksize, stride, pad, scale=None, shift=None, residua
         raise ValueError("packed weight %s does not match Cin=%d taps=%d" % (tuple(w_packed.shape), Cx + C2, KH * KW))
     Ho = (H * up + 2 * pad - KH) // stride + 1
     Wo = (W * up + 2 * pad - KW) // stride + 1
-    y = torch.empty(B, Ho, Wo, Cout, dtype=tdt, device=x.device)
+    y = torch.empty(B, Ho, Wo, Cout, dtype=torch.float32 if out_f32 else tdt, device=x.device)
     for name, t in (("scale", scale), ("shift", shift)):
         if t is not None:
             _f32c(t, name, (Cout,))
-    if residual is not None and (residual.dtype != tdt or tuple(residual.shape) != tuple(y.shape)
+    if residual is not None and (residual.dtype != tdt or tuple(residual.shape) != (B, Ho, Wo, Cout)
                                  or not residual.is_contiguous()):
         raise ValueError("residual must match the output")
     if stats is not None:
@@ -395,11 +445,11 @@ def conv2d_nhwc(x, w_packed, ksize, stride, pad, scale=None, shift=None, residua
     if _recorder is not None:
         _recorder.add(0, (x, x2, w_packed, scale, shift, residual, y, stats), x=x, x2=x2, w=w_packed, scale=scale,
                       shift=shift, residual=residual, y=y, stats=stats, B=B, H=H, W=W, Cx=Cx, C2=C2, up=up, Cout=Cout,
-                      KH=KH, KW=KW, stride=stride, pad=pad, relu=1 if relu else 0, dt=dt)
+                      KH=KH, KW=KW, stride=stride, pad=pad, relu=act, dt=dt)
     with _timed(tag):
         N.check(N.lib().lss_conv2d_fwd(N.ptr(x), N.ptr(x2), N.ptr(w_packed), N.ptr(scale), N.ptr(shift),
                                        N.ptr(residual), N.ptr(y), N.ptr(stats), B, H, W, Cx, C2, up, Cout,
-                                       KH, KW, stride, pad, 1 if relu else 0, dt, N.stream()), "lss_conv2d_fwd")
+                                       KH, KW, stride, pad, act, dt, N.stream()), "lss_conv2d_fwd")
     return y
 
 

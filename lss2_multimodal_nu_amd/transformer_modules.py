@@ -15,6 +15,34 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from . import ops
+from .modules import _PRECISIONS, _needs_autograd, _to_nhwc, default_precision
+
+
+class _PackedLinear:
+    """One or more nn.Linear (stacked along the output dim) as a packed 1x1-conv
+    weight + bias for the MFMA conv kernel; rebuilt when a source tensor changes."""
+
+    def __init__(self, *linears):
+        self.linears = linears
+        self.key = None
+        self.w = self.bias = None
+
+    def get(self, dt):
+        key = (dt,) + tuple((l.weight.data_ptr(), l.weight._version, l.bias._version) for l in self.linears)
+        if key != self.key:
+            with torch.no_grad():
+                w = torch.cat([l.weight.detach().float() for l in self.linears], 0).contiguous()
+                self.w = ops.pack_conv_weight(w[:, :, None, None].contiguous(), dt)
+                self.bias = torch.cat([l.bias.detach().float() for l in self.linears], 0).contiguous()
+            self.key = key
+        return self.w, self.bias
+
+    def run(self, x, dt, act=ops.ACT_NONE, residual=None, out_f32=False):
+        """x (B,H,W,Cin) NHWC in dt -> (B,H,W,Cout)."""
+        w, b = self.get(dt)
+        return ops.conv2d_nhwc(x, w, (1, 1), 1, 0, None, b, residual, act, dt=dt, out_f32=out_f32, tag="linear")
+
 
 class PositionEmbeddingSine(nn.Module):
     """(B, C, H, W) -> (B, 2*num_pos_feats, H, W): first half encodes the row, second
@@ -110,6 +138,26 @@ class TransformerEncoderLayer(nn.Module):
         self.dropout1 = nn.Dropout(dropout)
         self.dropout2 = nn.Dropout(dropout)
         self.activation = nn.GELU()
+        a = self.self_attn
+        self._p_ol = _PackedLinear(a.sampling_offsets, a.attention_weights)  # one GEMM: [offsets | logits]
+        self._p_val = _PackedLinear(a.value_proj)
+        self._p_out = _PackedLinear(a.output_proj)
+        self._p_l1 = _PackedLinear(self.linear1)
+        self._p_l2 = _PackedLinear(self.linear2)
+
+    def forward_nhwc(self, src, pos_table, ref_x, ref_y, dt):
+        """HIP path.  src (B,H,W,256) NHWC in dt; pos_table (H*W,256) fp32 -> (B,H,W,256) in dt.
+        Pre-LayerNorm sums and the sampling offsets stay fp32."""
+        tdt = src.dtype
+        q = ops.add_pos(src, pos_table)
+        ol = self._p_ol.run(q, dt, out_f32=True)
+        val = self._p_val.run(src, dt)
+        att = ops.deform_attn(val, ol, ref_x, ref_y, self.self_attn.n_heads, self.self_attn.n_points)
+        s1 = self._p_out.run(att, dt, residual=src, out_f32=True)
+        x1 = ops.layernorm(s1, self.norm1.weight.detach(), self.norm1.bias.detach(), self.norm1.eps, tdt)
+        ff = self._p_l1.run(x1, dt, act=ops.ACT_GELU)
+        s2 = self._p_l2.run(ff, dt, residual=x1, out_f32=True)
+        return ops.layernorm(s2, self.norm2.weight.detach(), self.norm2.bias.detach(), self.norm2.eps, tdt)
 
     def forward(self, src, pos, reference_points):
         """src (B, N, C); pos (B, C, H, W); reference_points (B, N, 2)."""
@@ -120,11 +168,29 @@ class TransformerEncoderLayer(nn.Module):
 
 
 class LightweightBEVTransformer(nn.Module):
-    def __init__(self, d_model=256, n_heads=8, dim_feedforward=1024, dropout=0.1):
+    def __init__(self, d_model=256, n_heads=8, dim_feedforward=1024, dropout=0.1, precision=None):
         super().__init__()
         self.d_model = d_model
         self.pos_encoder = PositionEmbeddingSine(d_model // 2, normalize=True)
         self.encoder = TransformerEncoderLayer(d_model, n_heads, dim_feedforward, dropout)
+        self.precision = precision
+        self._tables = {}
+
+    def _grid_tables(self, H, W, device):
+        key = (H, W, str(device))
+        t = self._tables.get(key)
+        if t is None:
+            t = self._tables[key] = (self.pos_encoder.table(H, W, device).contiguous(),
+                                     torch.linspace(0, 1, W, device=device), torch.linspace(0, 1, H, device=device))
+        return t
+
+    def forward_nhwc(self, x, dt):
+        """(B,H,W,256) NHWC in dt -> same shape/dtype, on the HIP kernels."""
+        B, H, W, C = x.shape
+        if C != 256 or self.encoder.self_attn.n_heads != 8 or self.encoder.self_attn.n_points != 8:
+            raise RuntimeError("the HIP transformer path is built for d_model=256, 8 heads, 8 points")
+        pos, ref_x, ref_y = self._grid_tables(H, W, x.device)
+        return self.encoder.forward_nhwc(x, pos, ref_x, ref_y, dt)
 
     @staticmethod
     def reference_points(H, W, device):
@@ -135,6 +201,9 @@ class LightweightBEVTransformer(nn.Module):
     def forward(self, x):
         """(B, C, H, W) -> (B, C, H, W)."""
         B, C, H, W = x.shape
+        if not _needs_autograd(self, x):
+            dt = _PRECISIONS[self.precision or default_precision()]
+            return ops.nhwc_to_nchw(self.forward_nhwc(_to_nhwc(x, dt), dt), dt)
         pos = self.pos_encoder(x)
         ref = self.reference_points(H, W, x.device).expand(B, -1, -1)
         y = self.encoder(x.flatten(2).permute(0, 2, 1), pos, ref)

@@ -147,3 +147,118 @@ def test_vovnet_full_size_vs_oracle(ver, prec):
     bidx = np.broadcast_to(np.arange(B).reshape(B, 1, 1, 1, 1), kept.shape)
     occ[bidx[kept], idx[..., 0][kept], idx[..., 1][kept]] = True
     assert float(bev.cpu().numpy()[~np.broadcast_to(occ[:, None], bev.shape)].__abs__().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------
+# BEV transformer
+# ---------------------------------------------------------------------------
+from lss2_multimodal_nu_amd import ops  # noqa: E402
+from lss2_multimodal_nu_amd import transformer_modules as tm  # noqa: E402
+
+
+def _wide(sd, key, scale):
+    sd[key] = sd[key] * float(scale)
+    return sd
+
+
+def test_add_pos_and_layernorm_kernels():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 7, 9, 256, generator=g)
+    pos = torch.randn(63, 256, generator=g)
+    gamma, beta = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    for dt in (torch.float32, torch.bfloat16):
+        xd = x.to(dt).cuda()
+        q = ops.add_pos(xd, pos.cuda())
+        want = xd.float().cpu() + pos.view(1, 7, 9, 256)
+        assert q.dtype == dt and rel(q, want)[0] <= (1e-6 if dt == torch.float32 else 8e-3)
+        y = ops.layernorm(xd, gamma.cuda(), beta.cuda(), 1e-5, torch.float32)
+        ref = torch.nn.functional.layer_norm(xd.float().cpu(), (256,), gamma, beta, 1e-5)
+        assert rel(y, ref)[0] <= 2e-6
+        yb = ops.layernorm(xd, gamma.cuda(), beta.cuda(), 1e-5, torch.bfloat16)
+        assert yb.dtype == torch.bfloat16 and rel(yb, ref)[0] <= 8e-3
+
+
+@pytest.mark.parametrize("H,W", [(12, 12), (40, 40), (9, 14)])
+def test_deform_attn_kernel_vs_oracle(H, W):
+    """Sampling core alone, offsets large enough to leave the grid on every side."""
+    g = torch.Generator().manual_seed(H * 100 + W)
+    B = 2
+    val = torch.randn(B, H, W, 256, generator=g)
+    ol = torch.cat([torch.randn(B, H, W, 128, generator=g) * 6.0, torch.randn(B, H, W, 64, generator=g) * 2.0], -1)
+    ref_x, ref_y = torch.linspace(0, 1, W), torch.linspace(0, 1, H)
+    out = ops.deform_attn(val.cuda(), ol.contiguous().cuda(), ref_x.cuda(), ref_y.cuda())
+    # oracle: same arithmetic through vovnet_oracle's explicit bilinear gather
+    off = ol[..., :128].reshape(B, H * W, 8, 8, 2)
+    aw = torch.softmax(ol[..., 128:].reshape(B, H * W, 8, 8), -1)
+    gy, gx = torch.meshgrid(ref_y, ref_x, indexing="ij")
+    pts = torch.stack([gx, gy], -1).view(-1, 2)
+    loc = (pts[None, :, None, None, :] + off / H).clamp(0, 1)
+    v = val.view(B, H, W, 8, 32)
+    want = torch.zeros(B, H * W, 8, 32)
+    for h in range(8):
+        gg = loc[:, :, h] * 2.0 - 1.0
+        px = ((gg[..., 0] + 1) * W - 1) / 2
+        py = ((gg[..., 1] + 1) * H - 1) / 2
+        s = vo.bilinear_zero_pad(v[:, :, :, h], px.reshape(B, -1), py.reshape(B, -1)).view(B, H * W, 8, 32)
+        want[:, :, h] = (s * aw[:, :, h, :, None]).sum(2)
+    assert rel(out.view(B, H * W, 8, 32), want)[0] <= 1e-5
+    out_b = ops.deform_attn(val.bfloat16().cuda(), ol.contiguous().cuda(), ref_x.cuda(), ref_y.cuda())
+    assert out_b.dtype == torch.bfloat16 and rel(out_b.view(B, H * W, 8, 32), want)[0] <= 1e-2
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_bev_transformer_native(golden, prec):
+    g = golden("g11_bev_transformer")
+    m = tm.LightweightBEVTransformer(256, 8, 1024, 0.1, precision=prec)
+    m.load_state_dict(_wide(vo.seeded_state(vo.transformer_shapes(), int(g["seed"])),
+                            "encoder.self_attn.sampling_offsets.bias", g["bias_scale"]))
+    m = m.cuda().eval()
+    with torch.no_grad():
+        out = m(t(g["x"]).cuda())
+    assert out.shape == g["out"].shape and out.dtype == torch.float32
+    mx, l2 = rel(out, g["out"])
+    assert l2 <= (2e-5 if prec == "fp32" else 2e-2) and mx <= (5e-5 if prec == "fp32" else 6e-2), (mx, l2)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_bev_encoder_transformer_native(golden, prec):
+    g = golden("g11_bev_encoder_transformer")
+    m = mv.BEVEncoderTransformer(128, 4, precision=prec)
+    m.load_state_dict(_wide(vo.seeded_state(vo.bev_encoder_transformer_shapes(128, 4), int(g["seed"])),
+                            "transformer.encoder.self_attn.sampling_offsets.bias", g["bias_scale"]))
+    m = m.cuda().eval()
+    with torch.no_grad():
+        seg, refined = m(t(g["x"]).cuda())
+    assert seg.shape == g["seg"].shape and refined.shape == g["refined"].shape
+    tol = 5e-5 if prec == "fp32" else 6e-2
+    assert rel(refined, g["refined"])[0] <= tol and rel(seg, g["seg"])[0] <= tol, (rel(refined, g["refined"]), rel(seg, g["seg"]))
+
+
+def test_bev_encoder_transformer_full_size_vs_oracle():
+    """200 x 200 tokens, bf16 conv math, against the CPU oracle."""
+    sd = vo.seeded_state(vo.bev_encoder_transformer_shapes(128, 4), 31)
+    m = mv.BEVEncoderTransformer(128, 4, precision="bf16")
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    x = t(np.random.RandomState(9).randn(1, 128, 200, 200).astype(np.float32))
+    with torch.no_grad():
+        seg, refined = m(x.cuda())
+    seg_ref, refined_ref = vo.bev_encoder_transformer(x, sd)
+    assert rel(refined, refined_ref)[1] <= 2e-2 and rel(seg, seg_ref)[1] <= 2e-2
+
+
+def test_vovnet_model_forward_smoke():
+    """Whole VoVNetBEVTransformer.forward on trunk maps: native inference == library path."""
+    B = 1
+    conf = dict(final_dim=(128, 352), Ncams=6, cams=list("abcdef"))
+    torch.manual_seed(2)
+    m = L.compile_model_vovnet_transformer(B, GRID, conf, 4, lss_version="v2", precision="fp32").cuda().eval()
+    gen = np.random.RandomState(6)
+    feats = {"c3": t(gen.randn(6, 768, 8, 22).astype(np.float32)).cuda(),
+             "c4": t(gen.randn(6, 1024, 4, 11).astype(np.float32)).cuda()}
+    calib = lo.synthetic_rig(B, 6, seed=1)
+    with torch.no_grad():
+        seg, act, desc = m(feats, *calib)
+    assert seg.shape == (B, 4, 200, 200) and act.shape == (B, 4) and desc.shape == (B, 8)
+    seg2, act2, desc2 = m(feats, *calib)  # grad enabled: torch ops for the heads/encoder, HIP splat
+    assert rel(seg, seg2.detach())[1] <= 1e-3 and rel(act, act2.detach())[0] <= 1e-3
