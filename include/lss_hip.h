@@ -57,6 +57,9 @@ extern "C" {
 #define LSS_ACT_RELU 1
 #define LSS_ACT_GELU 2 /* 0.5 x (1 + erf(x / sqrt 2)), torch.nn.GELU() */
 #define LSS_OUT_F32 16
+/* lss_conv2d_fwd, 1x1 bf16 only: y is written head-major, (B, Cout/32, Ho*Wo, 32), the
+ * layout the deformable-attention gather reads with the fewest cache lines */
+#define LSS_OUT_HEAD_MAJOR32 32
 
 int lss_abi_version(void);
 /* Static string for a return code of this library (never NULL). */
@@ -210,16 +213,21 @@ int lss_add_pos_fwd(const void* x, const float* pos, int B, int T, int C, int dt
 
 /* Deformable attention core.  replaces: src/transformer_modules.py:117-156 (views,
  *  softmax over points, sampling locations, the per-head grid_sample loop, weighting).
- *   value          (B, H, W, C) in `dt` = value_proj(src)
+ *   value          value_proj(src) in `dt`, (B, H, W, C) or head-major (see value_layout)
  *   offsets_logits (B*H*W, 192) fp32: [0,128) = sampling_offsets(q) as (head, point, xy),
  *                  [128,192) = attention_weights(q) as (head, point)
+ *   token_bias     (H*W, 192) fp32 or NULL: added to every sample's offsets_logits row of the
+ *                  same token.  With token_bias = pos @ [W_off; W_attn]^T the two linears can
+ *                  run on src instead of q = src + pos (linearity), so q is never formed
  *   ref_x (W), ref_y (H) fp32 = torch.linspace(0, 1, n)  (:243-244)
  *   out            (B, H*W, C) in `dt`, ready for output_proj
  * Sampling is bilinear with zero padding at align_corners=False pixel coordinates, both
  * offset axes divided by H as the reference does (:124). */
-int lss_deform_attn_fwd(const void* value, const float* offsets_logits, const float* ref_x,
-                        const float* ref_y, int B, int H, int W, int n_heads, int n_points, int C,
-                        int dt, void* out, void* stream);
+#define LSS_VALUE_NHWC 0       /* value (B, H*W, heads*32) */
+#define LSS_VALUE_HEAD_MAJOR 1 /* value (B, heads, H*W, 32): what LSS_OUT_HEAD_MAJOR32 writes */
+int lss_deform_attn_fwd(const void* value, int value_layout, const float* offsets_logits,
+                        const float* token_bias, const float* ref_x, const float* ref_y, int B, int H,
+                        int W, int n_heads, int n_points, int C, int dt, void* out, void* stream);
 
 /* nn.LayerNorm(C) over rows.  replaces: src/transformer_modules.py:204,208 (norm1, norm2)
  *   x (rows, C) in x_dt; y (rows, C) in y_dt; gamma, beta (C) fp32 */

@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblss_hip.so")
 
 BEV_NCHW_F32, BEV_NHWC_F32, BEV_NHWC_BF16 = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_GELU, OUT_F32 = 0, 1, 2, 16
+ACT_NONE, ACT_RELU, ACT_GELU, OUT_F32, OUT_HEAD_MAJOR32 = 0, 1, 2, 16, 32
+VALUE_NHWC, VALUE_HEAD_MAJOR = 0, 1
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 
@@ -29,7 +30,7 @@ SIGNATURES = {
     "lss_camencode_v2_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp] + [_i] * 6 + [_vp, _vp, _vp]),
     "lss_depth_fuse_softmax_fwd": (_i, [_vp] * 5 + [_i] * 6 + [_vp, _vp]),
     "lss_add_pos_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "lss_deform_attn_fwd": (_i, [_vp] * 4 + [_i] * 7 + [_vp, _vp]),
+    "lss_deform_attn_fwd": (_i, [_vp, _i] + [_vp] * 4 + [_i] * 7 + [_vp, _vp]),
     "lss_layernorm_fwd": (_i, [_vp, _i, _vp, _vp, ctypes.c_longlong, _i, ctypes.c_float, _vp, _i, _vp]),
     "lss_lift_splat_fwd": (_i, [_vp] * 3 + [_i] * 9 + [_vp, _i, _vp]),
     "lss_lift_splat_bwd": (_i, [_vp, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp, _vp]),

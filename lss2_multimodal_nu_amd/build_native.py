@@ -25,6 +25,7 @@ SOURCES = {
     "conv_mfma.hip": [],
     "layout.hip": [],
     "bev_transformer.hip": [],
+    "linear_mfma.hip": [],
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-variable",
           "-Wno-unused-but-set-variable"]

@@ -20,6 +20,10 @@
 
 #include "lss_common.h"
 
+int lss_linear_bf16_launch(const void* x, const void* w, const float* scale, const float* shift,
+                           const void* residual, void* y, long long M, int N, int K, int act,
+                           int out_f32, int group_hw, hipStream_t st);  // linear_mfma.hip
+
 namespace {
 
 struct ConvArgs {
@@ -842,7 +846,8 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   a.M = (int)M;
   a.relu = relu & 3;
   a.out_f32 = (relu & LSS_OUT_F32) != 0;
-  if (a.relu == 3 || (relu & ~(3 | LSS_OUT_F32)) != 0) return LSS_E_LAYOUT;
+  const bool head_major = (relu & LSS_OUT_HEAD_MAJOR32) != 0;
+  if (a.relu == 3 || (relu & ~(3 | LSS_OUT_F32 | LSS_OUT_HEAD_MAJOR32)) != 0) return LSS_E_LAYOUT;
   a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0;
   a.ry = a.Hin > 1 ? (float)(H - 1) / (float)(a.Hin - 1) : 0.f;
   a.rx = a.Win > 1 ? (float)(W - 1) / (float)(a.Win - 1) : 0.f;
@@ -859,9 +864,16 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   // 1x1 / stride 1: the token-major linear layers of the BEV transformer and the 1x1 convs
   if (dt == LSS_DT_BF16 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && !fused && a.Cin % 64 == 0 &&
       getenv("LSS_CONV_DIRECT") == nullptr) {
+    // a 1x1 conv over NHWC is a row-major GEMM over the B*H*W pixel rows (linear_mfma.hip);
+    // narrow outputs and the BN-statistics variant stay on the tiled conv kernel
+    if (a.Cout >= 64 && a.stats == nullptr && (head_major || getenv("LSS_LINEAR_CONV") == nullptr))
+      return lss_linear_bf16_launch(x, w_packed, scale, shift, residual, y, M, Cout, a.Cin, a.relu, a.out_f32,
+                                    head_major ? a.Ho * a.Wo : 0, st);
+    if (head_major) return LSS_E_LAYOUT;
     launch_conv_lds<0, 1, 1, 0>(a, st);
     return lss_launch_status();
   }
+  if (head_major) return LSS_E_LAYOUT;  // only the GEMM kernel writes that layout
   if (dt == LSS_DT_BF16) {
     if (fused) hipLaunchKernelGGL((conv_direct_kernel<unsigned short, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_direct_kernel<unsigned short, false>), grid, dim3(256), 0, st, a);

@@ -8,7 +8,7 @@ import torch
 
 from . import _native as N
 from ._native import (ACT_GELU, ACT_NONE, ACT_RELU, BEV_NCHW_F32, BEV_NHWC_BF16, BEV_NHWC_F32, DT_BF16,  # noqa: F401
-                      DT_F32, OUT_F32)
+                      DT_F32, OUT_F32, OUT_HEAD_MAJOR32, VALUE_HEAD_MAJOR, VALUE_NHWC)
 
 
 def _f32c(t, name, shape=None):
@@ -369,17 +369,29 @@ def add_pos(x, pos):
     return q
 
 
-def deform_attn(value, offsets_logits, ref_x, ref_y, n_heads=8, n_points=8):
-    """value (B,H,W,256) fp32|bf16; offsets_logits (B,H,W,192) fp32 -> (B,H,W,256) in value's dtype."""
-    B, H, W, C = value.shape
+def deform_attn(value, offsets_logits, ref_x, ref_y, n_heads=8, n_points=8, token_bias=None):
+    """value fp32|bf16: (B,H,W,256) NHWC, or head-major (B,8,H*W,32) (conv2d_nhwc(head_major=True));
+    offsets_logits (B,H,W,192) fp32; token_bias (H*W,192) fp32 or None (per-token addend shared by
+    all samples) -> (B,H,W,256) NHWC in value's dtype."""
+    B, H, W = offsets_logits.shape[:3]
+    C = n_heads * 32
+    if tuple(value.shape) == (B, H, W, C):
+        layout = VALUE_NHWC
+    elif tuple(value.shape) == (B, n_heads, H * W, 32):
+        layout = VALUE_HEAD_MAJOR
+    else:
+        raise ValueError("value %s is neither (B,H,W,%d) nor (B,%d,H*W,32)" % (tuple(value.shape), C, n_heads))
     if not value.is_contiguous() or value.dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError("value must be contiguous fp32/bf16 NHWC")
+        raise ValueError("value must be contiguous fp32/bf16")
     _f32c(offsets_logits, "offsets_logits", (B, H, W, n_heads * n_points * 3))
     _f32c(ref_x, "ref_x", (W,))
     _f32c(ref_y, "ref_y", (H,))
-    out = torch.empty_like(value)
+    if token_bias is not None:
+        _f32c(token_bias, "token_bias", (H * W, n_heads * n_points * 3))
+    out = torch.empty(B, H, W, C, dtype=value.dtype, device=value.device)
     with _timed("deform_attn"):
-        N.check(N.lib().lss_deform_attn_fwd(N.ptr(value), N.ptr(offsets_logits), N.ptr(ref_x), N.ptr(ref_y), B, H, W,
+        N.check(N.lib().lss_deform_attn_fwd(N.ptr(value), layout, N.ptr(offsets_logits), N.ptr(token_bias), N.ptr(ref_x),
+                                            N.ptr(ref_y), B, H, W,
                                             n_heads, n_points, C, DT_F32 if value.dtype == torch.float32 else DT_BF16,
                                             N.ptr(out), N.stream()), "lss_deform_attn_fwd")
     return out
@@ -413,12 +425,13 @@ def pack_conv_weight(w_oihw, dt):
 
 
 def conv2d_nhwc(x, w_packed, ksize, stride, pad, scale=None, shift=None, residual=None, relu=False,
-                x2=None, up=1, stats=None, dt=DT_BF16, tag="conv2d_fwd", out_f32=False):
+                x2=None, up=1, stats=None, dt=DT_BF16, tag="conv2d_fwd", out_f32=False, head_major=False):
     """K8.  x (B,H,W,Cx) NHWC in `dt`; x2 (B,H*up,W*up,C2) optional skip tensor
     (conv input = cat([x2, upsample(x, up)])).  Returns y (B,Ho,Wo,Cout) in `dt`
-    (fp32 with out_f32).  relu: False/True or an ACT_* code (ACT_GELU = erf GELU)."""
+    (fp32 with out_f32).  relu: False/True or an ACT_* code (ACT_GELU = erf GELU).
+    head_major (1x1 bf16 convs): y is laid out (B, Cout/32, Ho*Wo, 32) and returned with that shape."""
     tdt = _TORCH_DT[dt]
-    act = int(relu) | (OUT_F32 if (out_f32 and dt == DT_BF16) else 0)
+    act = int(relu) | (OUT_F32 if (out_f32 and dt == DT_BF16) else 0) | (OUT_HEAD_MAJOR32 if head_major else 0)
     B, H, W, Cx = x.shape
     KH, KW = ksize
     taps, Cout, Cin = w_packed.shape
@@ -450,7 +463,7 @@ def conv2d_nhwc(x, w_packed, ksize, stride, pad, scale=None, shift=None, residua
         N.check(N.lib().lss_conv2d_fwd(N.ptr(x), N.ptr(x2), N.ptr(w_packed), N.ptr(scale), N.ptr(shift),
                                        N.ptr(residual), N.ptr(y), N.ptr(stats), B, H, W, Cx, C2, up, Cout,
                                        KH, KW, stride, pad, act, dt, N.stream()), "lss_conv2d_fwd")
-    return y
+    return y.view(B, Cout // 32, Ho * Wo, 32) if head_major else y
 
 
 def pack_conv_weight_s2d(w_oihw, pad):

@@ -204,6 +204,24 @@ def test_deform_attn_kernel_vs_oracle(H, W):
     assert rel(out.view(B, H * W, 8, 32), want)[0] <= 1e-5
     out_b = ops.deform_attn(val.bfloat16().cuda(), ol.contiguous().cuda(), ref_x.cuda(), ref_y.cuda())
     assert out_b.dtype == torch.bfloat16 and rel(out_b.view(B, H * W, 8, 32), want)[0] <= 1e-2
+    # head-major value layout (what the value_proj GEMM writes) + the per-token bias split
+    vh = val.view(B, H * W, 8, 32).permute(0, 2, 1, 3).contiguous()
+    tb = torch.randn(H * W, 192, generator=g)
+    out_h = ops.deform_attn(vh.cuda(), (ol - tb.view(1, H, W, 192)).contiguous().cuda(), ref_x.cuda(), ref_y.cuda(),
+                            token_bias=tb.cuda())
+    assert out_h.shape == (B, H, W, 256) and rel(out_h.view(B, H * W, 8, 32), want)[0] <= 2e-5
+
+
+def test_head_major_linear_output():
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 9, 14, 256, generator=g).bfloat16().cuda()
+    w = (torch.randn(256, 256, 1, 1, generator=g) / 16).cuda()
+    b = torch.randn(256, generator=g).cuda()
+    wp = ops.pack_conv_weight(w, ops.DT_BF16)
+    y = ops.conv2d_nhwc(x, wp, (1, 1), 1, 0, None, b, None, False)
+    yh = ops.conv2d_nhwc(x, wp, (1, 1), 1, 0, None, b, None, False, head_major=True)
+    assert yh.shape == (2, 8, 9 * 14, 32)
+    assert torch.equal(yh.permute(0, 2, 1, 3).reshape(2, 9, 14, 256), y)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])

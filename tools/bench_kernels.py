@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-kernel micro-benchmark on one GPU: every BevEncode conv shape at batch B
 (bf16) and the L1 kernels, timed with HIP events on the launch stream.
-    python tools/bench_kernels.py [--batch 4] [--iters 30] [--only conv|l1]"""
+    python tools/bench_kernels.py [--batch 4] [--iters 30] [--only conv|l1|vovnet|gemm]
+`--only vovnet` times BASELINE configs[3] (vovnet shapes, C=128, BEV transformer) stage by stage."""
 import argparse
 import os
 import sys
@@ -106,6 +107,67 @@ def main():
             print("%-28s %10.1f   %7.0f GB/s written" % ("K5 lift-splat " + nm, us, B * 64 * 200 * 200 * nbytes / us / 1e3))
         G = torch.randn(B, 200, 200, 64, device="cuda").permute(0, 3, 1, 2)
         print("%-28s %10.1f" % ("K7 lift-splat bwd (NHWC G)", timeit(lambda: ops.lift_splat_bwd(G, ws.voxel, depth, feat, (B, N, D, fH, fW, C), (200, 200, 1)), args.iters)))
+    if args.only == "vovnet":
+        vovnet(args)
+    if args.only == "gemm":
+        gemm(args)
+
+
+def gemm(args):
+    """1x1 convs = token-major GEMMs of the BEV transformer (linear_mfma.hip), bf16, no epilogue extras."""
+    for (B, H, W, K, N) in [(8, 200, 200, 256, 1024), (8, 200, 200, 1024, 256), (8, 200, 200, 256, 256),
+                            (8, 200, 200, 256, 192), (8, 200, 200, 128, 256), (1, 128, 128, 256, 1024)]:
+        x = torch.randn(B, H, W, K, device="cuda").to(torch.bfloat16)
+        w = ops.pack_conv_weight(torch.randn(N, K, 1, 1, device="cuda") * 0.05, ops.DT_BF16)
+        b = torch.randn(N, device="cuda")
+        us = timeit(lambda: ops.conv2d_nhwc(x, w, (1, 1), 1, 0, None, b, None, False), args.iters)
+        fl = 2.0 * B * H * W * K * N
+        print("M=%7d K=%4d N=%4d %9.1f us %8.1f TF/s   in %4.0f MB  out %4.0f MB" %
+              (B * H * W, K, N, us, fl / us / 1e6, B * H * W * K * 2 / 1e6, B * H * W * N * 2 / 1e6))
+
+
+def vovnet(args):
+    """BASELINE configs[3]: trunk maps (B*6,768,8,22)/(B*6,1024,4,11) -> C=128 lift-splat ->
+    BEVEncoderTransformer, bf16 conv math.  Whole-model time with plain events, then one pass
+    with a bracket around every native launch (each bracket adds a few us of idle)."""
+    import numpy as np
+
+    import lss2_multimodal_nu_amd as L
+    from oracle import lss_oracle as lo
+    B = args.batch
+    grid = dict(xbound=[-50.0, 50.0, 0.5], ybound=[-50.0, 50.0, 0.5], zbound=[-10.0, 10.0, 20.0],
+                dbound=[4.0, 45.0, 1.0])
+    conf = dict(final_dim=(128, 352), Ncams=6, cams=list("abcdef"))
+    torch.manual_seed(0)
+    m = L.compile_model_vovnet_transformer(B, grid, conf, 4, lss_version="v2", precision="bf16").cuda().eval()
+    gen = np.random.RandomState(0)
+    c3 = torch.from_numpy(gen.randn(B * 6, 768, 8, 22).astype(np.float32)).cuda()
+    c4 = torch.from_numpy(gen.randn(B * 6, 1024, 4, 11).astype(np.float32)).cuda()
+    calib = lo.synthetic_rig(B, 6, train_aug=True, seed=0)
+    dt = ops.DT_BF16
+
+    def bev_branch():
+        g = m.get_voxels(c3, c4, *calib, layout=ops.BEV_NHWC_BF16)
+        return m.bev_encoder.forward_nhwc(g.permute(0, 2, 3, 1), dt)
+
+    with torch.no_grad():
+        us = timeit(bev_branch, args.iters)
+        us_l1 = timeit(lambda: m.get_voxels(c3, c4, *calib, layout=ops.BEV_NHWC_BF16), args.iters)
+        print("vovnet BEV branch (B=%d, bf16): %.1f us/step = %.0f frames/s; lift-splat level %.1f us"
+              % (B, us, B / us * 1e6, us_l1))
+        tm = ops.KernelTimer(fine=True)
+        ops.set_timer(tm)
+        for _ in range(5):
+            bev_branch()
+        torch.cuda.synchronize()
+        ops.set_timer(None)
+    for tag, (n, ms) in sorted(tm.totals_ms().items(), key=lambda kv: -kv[1][1]):
+        print("  %-24s %3d launches/step %9.1f us/step" % (tag, n // 5, ms / 5 * 1e3))
+    for tag in ("linear", "conv2d_fwd", "layernorm"):  # per launch, in issue order (mean of the 5 passes)
+        sp = tm.spans.get(tag, [])
+        n = len(sp) // 5
+        print("  %s per launch: %s" % (tag, "  ".join(
+            "%.0f" % (sum(sp[p * n + i][0].elapsed_time(sp[p * n + i][1]) for p in range(5)) / 5 * 1e3) for i in range(n))))
 
 
 if __name__ == "__main__":
