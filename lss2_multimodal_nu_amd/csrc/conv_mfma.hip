@@ -862,17 +862,14 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
     return lss_launch_status();
   }
   // 1x1 / stride 1: the token-major linear layers of the BEV transformer and the 1x1 convs
-  if (dt == LSS_DT_BF16 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && !fused && a.Cin % 64 == 0 &&
-      getenv("LSS_CONV_DIRECT") == nullptr) {
-    // a 1x1 conv over NHWC is a row-major GEMM over the B*H*W pixel rows (linear_mfma.hip);
-    // narrow outputs and the BN-statistics variant stay on the tiled conv kernel
-    if (a.Cout >= 64 && a.stats == nullptr && (head_major || getenv("LSS_LINEAR_CONV") == nullptr))
-      return lss_linear_bf16_launch(x, w_packed, scale, shift, residual, y, M, Cout, a.Cin, a.relu, a.out_f32,
-                                    head_major ? a.Ho * a.Wo : 0, st);
-    if (head_major) return LSS_E_LAYOUT;
-    launch_conv_lds<0, 1, 1, 0>(a, st);
-    return lss_launch_status();
-  }
+  // a 1x1 / stride-1 conv over NHWC is a row-major GEMM over the B*H*W pixel rows
+  // (linear_mfma.hip): the token-major linear layers of the BEV transformer and the 1x1
+  // convs around it.  Narrow outputs (the 4-class heads: a 128-wide tile would be 97 % padding)
+  // and the BN-statistics variant stay on the direct kernel below.
+  if (dt == LSS_DT_BF16 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && !fused && a.Cin % 32 == 0 &&
+      a.Cout >= 64 && a.stats == nullptr && getenv("LSS_CONV_DIRECT") == nullptr)
+    return lss_linear_bf16_launch(x, w_packed, scale, shift, residual, y, M, Cout, a.Cin, a.relu, a.out_f32,
+                                  head_major ? a.Ho * a.Wo : 0, st);
   if (head_major) return LSS_E_LAYOUT;  // only the GEMM kernel writes that layout
   if (dt == LSS_DT_BF16) {
     if (fused) hipLaunchKernelGGL((conv_direct_kernel<unsigned short, true>), grid, dim3(256), 0, st, a);
