@@ -43,9 +43,13 @@ class _FoldedConv:
     """Packed weights + eval-mode BatchNorm folded into (scale, shift) for one
     conv of the HIP path; rebuilt only when a source tensor changes."""
 
-    def __init__(self, conv, bn=None, pack=True):
+    def __init__(self, conv, bn=None, pack=True, pad_in=None):
         self.conv, self.bn = conv, bn
         self.pack = pack  # False: only the folded (scale, shift) are wanted
+        # (at, n): insert n zero input channels at channel `at` of the packed weight - lets a
+        # skip tensor whose width is not a multiple of the kernels' 64-channel K block be
+        # zero-padded (its padding channels then meet zero weights)
+        self.pad_in = pad_in
         self.key = None
         self.w = self.scale = self.shift = None
 
@@ -72,6 +76,10 @@ class _FoldedConv:
         if key != self.key:
             with torch.no_grad():
                 w32 = self.conv.weight.detach().float().contiguous()
+                if self.pad_in is not None:
+                    at, n = self.pad_in
+                    w32 = torch.cat([w32[:, :at], w32.new_zeros(w32.shape[0], n, *w32.shape[2:]), w32[:, at:]],
+                                    1).contiguous()
                 # (the 1x1/2 conv reads parity phase (0,0) only: plain pack)
                 if not self.pack:
                     self.w = None
@@ -130,8 +138,19 @@ class Up(nn.Module):
         self.precision = precision
         self._f0 = _FoldedConv(self.conv[0], self.conv[1])
         self._f1 = _FoldedConv(self.conv[3], self.conv[4])
+        self._f0_c2 = None  # skip-tensor width the padded form of conv[0] was built for
 
     def _nhwc(self, x1, x2, dt):
+        kb = 64 if dt == ops.DT_BF16 else 8  # K block of the conv kernels
+        c2 = x2.shape[3]
+        if c2 % kb != 0:
+            # e.g. Encoder.up1: 160 skip channels (ref: src/modules.py:32).  Pad the skip tensor with
+            # zero channels up to the K block; the packed weight gets matching zero columns.
+            padc = kb - c2 % kb
+            if self._f0_c2 != c2:
+                self._f0 = _FoldedConv(self.conv[0], self.conv[1], pad_in=(c2, padc))
+                self._f0_c2 = c2
+            x2 = F.pad(x2, (0, padc))
         y = self._f0.run(x1, dt, relu=True, x2=x2, up=self.scale_factor)
         return self._f1.run(y, dt, relu=True)
 
@@ -176,6 +195,42 @@ class CamEncode(nn.Module):
     def forward(self, x):
         depth, x = self.get_depth_feat(x)
         return x
+
+
+class Encoder(nn.Module):
+    """Mirror of the reference's `Encoder` (src/modules.py:28-66) from the trunk's endpoints on:
+    `up1 = Up(448 + 160, 512)` fuses EfficientNet-B4's reduction_5 (1/32, 448 ch, upsampled x2)
+    with reduction_4 (1/16, 160 ch) into the (B*N, 512, H/16, W/16) map CamEncode consumes.
+
+    The EfficientNet itself is third-party (`efficientnet_pytorch`, a by-name weight fetch in the
+    reference) and is NOT bundled: `trunk` is any module whose call returns the endpoints
+    {'reduction_4': (B*N,160,H/16,W/16), 'reduction_5': (B*N,448,H/32,W/32)} for (B*N,3,H,W)
+    images (efficientnet_pytorch's `extract_endpoints` has exactly this contract); without a
+    trunk, `forward` takes that dict (or a (reduction_5, reduction_4) pair) directly.
+    `up1.*` state_dict keys equal the reference's."""
+
+    def __init__(self, trunk=None, c5=448, c4=160, precision=None):
+        super().__init__()
+        if trunk is not None:
+            self.trunk = trunk
+        self.up1 = Up(c5 + c4, 512, precision=precision)
+
+    def get_eff_depth(self, x):
+        if torch.is_tensor(x):
+            if getattr(self, "trunk", None) is None:
+                raise RuntimeError("got camera images but no trunk: pass trunk=<EfficientNet endpoints module> or "
+                                   "feed {'reduction_4': ..., 'reduction_5': ...}")
+            if x.dim() == 5:
+                x = x.reshape(-1, *x.shape[2:])
+            fn = getattr(self.trunk, "extract_endpoints", self.trunk)
+            x = fn(x)
+        if isinstance(x, dict):
+            x = (x["reduction_5"], x["reduction_4"])
+        r5, r4 = x
+        return self.up1(r5, r4)
+
+    def forward(self, x):
+        return self.get_eff_depth(x)
 
 
 class BasicBlock(nn.Module):

@@ -159,9 +159,32 @@ def test_bevencode_and_up_modules_vs_oracle(golden):
     g = golden("g9_up_x2_eval")
     up = L.Up(12, 6, scale_factor=2, precision="fp32")
     up.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_") and not k.startswith("sd_after_")})
-    # the reference fixture has 8+4 channels: not a multiple of the f32 K block (8) for x2 -> expect a loud error
+    # the reference fixture is 8+4 -> 6 -> 6 channels: the 4-channel skip tensor is zero-padded to the f32 K
+    # block, but the second conv's 6 input channels are not a multiple of it -> a loud error, no fallback
     with torch.no_grad(), pytest.raises(ValueError):
         up.cuda().eval()(torch.from_numpy(g["x1"]).cuda(), torch.from_numpy(g["x2"]).cuda())
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 3e-2)])
+def test_encoder_up1_from_trunk_endpoints(prec, tol):
+    """Encoder.up1 = Up(448+160, 512) on EfficientNet-B4 endpoint shapes (160 skip channels
+    are not a multiple of the 64-channel K block)."""
+    torch.manual_seed(5)
+    enc = L.Encoder(precision=prec)
+    assert [k for k in enc.state_dict()][:2] == ["up1.conv.0.weight", "up1.conv.1.weight"]
+    assert tuple(enc.up1.conv[0].weight.shape) == (512, 608, 3, 3)
+    randomize_bn(enc)
+    enc = enc.cuda().eval()
+    r5, r4 = torch.randn(6, 448, 4, 11), torch.randn(6, 160, 8, 22)
+    with torch.no_grad():
+        y = enc({"reduction_5": r5.cuda(), "reduction_4": r4.cuda()})
+        y2 = enc((r5.cuda(), r4.cuda()))
+    sd = {k: v.cpu() for k, v in enc.state_dict().items()}
+    ref = bo.up_block(r5, r4, sd, "up1", 2)
+    assert y.shape == (6, 512, 8, 22) and torch.equal(y, y2)
+    assert float((y.cpu() - ref).abs().max()) <= tol * float(ref.abs().max())
+    with pytest.raises(RuntimeError):
+        enc(torch.zeros(1, 6, 3, 128, 352).cuda())
 
 
 def test_camencode_module_vs_golden(golden):
