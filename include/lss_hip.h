@@ -261,6 +261,26 @@ int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packed,
                    int Cout, int KH, int KW, int stride, int pad, int relu, int dt,
                    void* stream);
 
+/* ---------------------------------------------------------------------------
+ * K8b  gradients of the convolutions (training; replaces the ConvolutionBackward autograd
+ *      nodes behind `loss.backward()`, train.py:61, for the convs of src/modules.py:22-27,
+ *      118-130 and torchvision's BasicBlock).
+ *
+ * Input gradient: dX = conv(dY, W') with W'[ci][tap'][co] = W[co][KH-1-ky][KW-1-kx][ci].
+ *   lss_conv2d_pack_weights_dgrad arranges W' as [tap'][Cin][Cout]; then call lss_conv2d_fwd
+ *   with x = dY (Cx = Cout), Cout = Cin, the same KH, KW, stride 1 and pad' = KH-1-pad.
+ * Weight gradient (3x3 / stride 1 / pad 1, bf16 NHWC operands, fp32 OIHW result):
+ *   x  (B,H,W,Cin) bf16 - the conv's input;  dy (B,H,W,Cout) bf16 - gradient of its raw output
+ *   workspace: lss_conv2d_wgrad_workspace_bytes bytes, 256-B aligned (channel-major copies of
+ *   both operands + fp32 split-K partials); dw_oihw (Cout,Cin,3,3) fp32, fully overwritten.
+ *   Cin % 8 == 0, Cout % 8 == 0.  Fixed summation order: bit-reproducible.
+ */
+int lss_conv2d_pack_weights_dgrad(const float* w_oihw, int Cout, int Cin, int KH, int KW, int dt,
+                                  void* w_packed, void* stream);
+size_t lss_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int lss_conv2d_wgrad(const void* x, const void* dy, int B, int H, int W, int Cin, int Cout,
+                     void* workspace, size_t workspace_bytes, float* dw_oihw, void* stream);
+
 /* Stride-2 convs (3x3 pad 1, 7x7 pad 3, and 1x1 pad 0 with the plain weight pack;
  * bf16) on the LDS-tiled MFMA kernel: the
  * conv is evaluated as a stride-1 conv over the 4 parity phases of the input

@@ -26,6 +26,7 @@ SOURCES = {
     "layout.hip": [],
     "bev_transformer.hip": [],
     "linear_mfma.hip": [],
+    "conv_grad.hip": [],
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-variable",
           "-Wno-unused-but-set-variable"]

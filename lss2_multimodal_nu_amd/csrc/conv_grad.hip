@@ -1,0 +1,203 @@
+// Gradients of the 3x3 / stride 1 / pad 1 bf16 NHWC convolution (the shape that carries
+// 95 % of BevEncode's FLOPs): the backward half of conv_mfma.hip's forward kernels.
+// replaces: the autograd nodes ConvolutionBackward of the convs in src/modules.py:22-27,
+//           118-130 (+ torchvision BasicBlock) that `loss.backward()` runs in train.py:61.
+//
+// dgrad  dX = conv3x3(dY, W') with W'[ci][ky][kx][co] = W[co][2-ky][2-kx][ci]: the FORWARD
+//        kernel on a differently packed weight (lss_conv2d_pack_weights_dgrad), nothing else.
+// wgrad  dW[co][ci][ky][kx] = sum_{b,y,x} dY[b,y,x,co] * X[b,y+ky-1,x+kx-1,ci] is, per tap, a
+//        GEMM whose K dimension is the pixel index.  NHWC has K as the SLOW dimension of both
+//        operands, so both are first transposed to channel-major rows over a zero-padded
+//        image grid (B, H+2, Wp), Wp = W+2 rounded up to 8:
+//          dYt[co][flat(b,y+1,x+1)] = dY[b,y,x,co]                       (zeros on the border)
+//          Xt_d[ci][flat(b,y',x')]  = Xpad[b][y'][x'+d],  d = -1, 0, +1  (three column-shifted copies)
+//        Then tap (ky,kx) is the plain K-contiguous GEMM  dYt . Xt_{kx-1}^T  with the second
+//        operand read (ky-1)*Wp elements further on - always 16-B aligned, which is why the
+//        column shift is materialised and the row shift is not.  The GEMM is linear_mfma.hip's
+//        kernel in split-K mode (grid.y = split x tap, fp32 partial tiles), followed by a
+//        fixed-order reduction over the splits (bit-reproducible; no atomics).
+#include "lss_common.h"
+
+int lss_wgrad_gemm_launch(const void* dyt, const void* const xt[3], float* partial, int M, int N,
+                          long long ld, long long split_k, int nsplit, int ntap, long long tap_row,
+                          hipStream_t st);  // linear_mfma.hip
+
+namespace {
+
+// OIHW fp32 -> [tap'][ci][co] with tap' = (KH-1-ky)*KW + (KW-1-kx): the weight of the conv
+// that maps dY (Cout channels) to dX (Cin channels)
+template <typename T>
+__global__ void pack_weights_dgrad_kernel(const float* __restrict__ w, int Cout, int Cin, int KH, int KW,
+                                          T* __restrict__ out) {
+  const size_t n = (size_t)Cout * Cin * KH * KW;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int co = e % Cout;
+    const size_t t = e / Cout;
+    const int ci = t % Cin;
+    const int tap = t / Cin;
+    const int ky = KH - 1 - tap / KW, kx = KW - 1 - tap % KW;
+    const float v = w[(((size_t)co * Cin + ci) * KH + ky) * KW + kx];
+    if (sizeof(T) == 2) reinterpret_cast<unsigned short*>(out)[e] = lss_f2bf(v);
+    else reinterpret_cast<float*>(out)[e] = v;
+  }
+}
+
+struct WgradGeom {
+  int B, H, W, Wp;
+  long long ktot;   // B*(H+2)*Wp rounded up to nsplit*32
+  long long ld;     // row stride of the channel-major copies: Wp lead + ktot + Wp tail
+  int nsplit;
+  long long split_k;
+};
+
+inline WgradGeom wgrad_geom(int B, int H, int W, int Cin, int Cout) {
+  WgradGeom g;
+  g.B = B; g.H = H; g.W = W;
+  g.Wp = (W + 2 + 7) / 8 * 8;
+  const long long k = (long long)B * (H + 2) * g.Wp;
+  // enough (tile, tap, split) workgroups for ~2.5 per CU
+  const long long tiles = (long long)lss_cdiv(Cout, 128) * lss_cdiv(Cin, 128) * 9;
+  int ns = (int)((640 + tiles - 1) / tiles);
+  const long long max_ns = k / (32 * 8) > 0 ? k / (32 * 8) : 1;  // at least 8 K-steps per split
+  if (ns > max_ns) ns = (int)max_ns;
+  if (ns < 1) ns = 1;
+  g.nsplit = ns;
+  g.split_k = ((k + ns - 1) / ns + 31) / 32 * 32;
+  g.ktot = g.split_k * ns;
+  g.ld = g.ktot + 2LL * g.Wp;
+  return g;
+}
+
+// One workgroup = one padded image row (b, y') x 64 channels.  NHWC row -> LDS tile ->
+// channel-major rows, `ncopy` column-shifted copies (1: d = 0; 3: d = -1, 0, +1).
+__global__ __launch_bounds__(256) void to_channel_major_kernel(const unsigned short* __restrict__ src,
+                                                               int B, int H, int W, int C, int Wp,
+                                                               long long ld, long long copy_stride,
+                                                               int ncopy, unsigned short* __restrict__ dst) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short tile[];  // [64][Wp + 8]
+  const int TS = Wp + 8;  // tile column j holds padded-image column x'' = j - 4
+  const int tid = threadIdx.x;
+  const int yp = blockIdx.x % (H + 2), b = blockIdx.x / (H + 2);
+  const int c0 = blockIdx.y * 64;
+  for (int e = tid; e < 64 * TS; e += 256) tile[e] = 0;
+  __syncthreads();
+  if (yp >= 1 && yp <= H) {
+    const unsigned short* row = src + ((size_t)(b * H + (yp - 1)) * W) * C;
+    for (int e = tid; e < W * 8; e += 256) {
+      const int px = e >> 3, part = e & 7;
+      const int c = c0 + part * 8;
+      if (c < C) {
+        const uint4 v = *reinterpret_cast<const uint4*>(row + (size_t)px * C + c);
+        const unsigned int u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          tile[(part * 8 + 2 * k) * TS + px + 1 + 4] = (unsigned short)(u[k] & 0xffff);
+          tile[(part * 8 + 2 * k + 1) * TS + px + 1 + 4] = (unsigned short)(u[k] >> 16);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const long long flat0 = ((long long)b * (H + 2) + yp) * Wp + Wp;  // + Wp: the lead guard row
+  const int chunks = Wp / 8;
+  for (int e = tid; e < ncopy * 64 * chunks; e += 256) {
+    const int ch = e % chunks;
+    const int c = (e / chunks) % 64;
+    const int copy = e / (chunks * 64);
+    if (c0 + c >= C) continue;
+    const int d = ncopy == 3 ? copy - 1 : 0;
+    const unsigned short* t = tile + c * TS + ch * 8 + d + 4;
+    uint4 o;
+    o.x = t[0] | ((unsigned int)t[1] << 16);
+    o.y = t[2] | ((unsigned int)t[3] << 16);
+    o.z = t[4] | ((unsigned int)t[5] << 16);
+    o.w = t[6] | ((unsigned int)t[7] << 16);
+    *reinterpret_cast<uint4*>(dst + (size_t)copy * copy_stride + (size_t)(c0 + c) * ld + flat0 + ch * 8) = o;
+  }
+}
+
+// dW (OIHW fp32) = sum over splits, in split order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int Cout, int Cin,
+                                    float* __restrict__ dw) {
+  const size_t n = (size_t)9 * Cout * Cin;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int ci = e % Cin;
+    const size_t t = e / Cin;
+    const int co = t % Cout;
+    const int tap = t / Cout;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * n + e];
+    dw[((size_t)co * Cin + ci) * 9 + tap] = s;
+  }
+}
+
+inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+extern "C" int lss_conv2d_pack_weights_dgrad(const float* w_oihw, int Cout, int Cin, int KH, int KW, int dt,
+                                             void* w_packed, void* stream) {
+  LSS_CHECK_PTR(w_oihw); LSS_CHECK_PTR(w_packed);
+  LSS_CHECK_POS(Cout); LSS_CHECK_POS(Cin); LSS_CHECK_POS(KH); LSS_CHECK_POS(KW);
+  const size_t n = (size_t)Cout * Cin * KH * KW;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  if (dt == LSS_DT_BF16)
+    hipLaunchKernelGGL(pack_weights_dgrad_kernel<unsigned short>, dim3(grid), dim3(256), 0, lss_stream(stream),
+                       w_oihw, Cout, Cin, KH, KW, reinterpret_cast<unsigned short*>(w_packed));
+  else if (dt == LSS_DT_F32)
+    hipLaunchKernelGGL(pack_weights_dgrad_kernel<float>, dim3(grid), dim3(256), 0, lss_stream(stream), w_oihw,
+                       Cout, Cin, KH, KW, reinterpret_cast<float*>(w_packed));
+  else
+    return LSS_E_LAYOUT;
+  return lss_launch_status();
+}
+
+extern "C" size_t lss_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const WgradGeom g = wgrad_geom(B, H, W, Cin, Cout);
+  return align256((size_t)3 * Cin * g.ld * 2) + align256((size_t)Cout * g.ld * 2) +
+         align256((size_t)g.nsplit * 9 * Cout * Cin * 4);
+}
+
+extern "C" int lss_conv2d_wgrad(const void* x, const void* dy, int B, int H, int W, int Cin, int Cout,
+                                void* workspace, size_t workspace_bytes, float* dw_oihw, void* stream) {
+  LSS_CHECK_PTR(x); LSS_CHECK_PTR(dy); LSS_CHECK_PTR(workspace); LSS_CHECK_PTR(dw_oihw);
+  LSS_CHECK_POS(B); LSS_CHECK_POS(H); LSS_CHECK_POS(W); LSS_CHECK_POS(Cin); LSS_CHECK_POS(Cout);
+  if (Cin % 8 != 0 || Cout % 8 != 0 || W > 4096) return LSS_E_SHAPE;
+  if (workspace_bytes < lss_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout)) return LSS_E_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return LSS_E_ALIGN;
+  const WgradGeom g = wgrad_geom(B, H, W, Cin, Cout);
+  hipStream_t st = lss_stream(stream);
+  unsigned char* ws = static_cast<unsigned char*>(workspace);
+  unsigned short* xt = reinterpret_cast<unsigned short*>(ws);
+  const size_t xt_bytes = align256((size_t)3 * Cin * g.ld * 2);
+  unsigned short* dyt = reinterpret_cast<unsigned short*>(ws + xt_bytes);
+  const size_t dyt_bytes = align256((size_t)Cout * g.ld * 2);
+  float* partial = reinterpret_cast<float*>(ws + xt_bytes + dyt_bytes);
+  // the lead guard row and everything past the image grid (K tail + tail guard row) must read
+  // as zeros; the grid itself (borders included) is rewritten below
+  const long long kimg = (long long)B * (H + 2) * g.Wp;
+  const size_t pitch = (size_t)g.ld * 2;
+  for (int which = 0; which < 2; ++which) {
+    unsigned char* base = which == 0 ? reinterpret_cast<unsigned char*>(xt) : reinterpret_cast<unsigned char*>(dyt);
+    const size_t rows = which == 0 ? (size_t)3 * Cin : (size_t)Cout;
+    hipError_t e = hipMemset2DAsync(base, pitch, 0, (size_t)g.Wp * 2, rows, st);
+    if (e == hipSuccess)
+      e = hipMemset2DAsync(base + ((size_t)g.Wp + kimg) * 2, pitch, 0, (size_t)(g.ld - g.Wp - kimg) * 2, rows, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  const size_t lds = (size_t)64 * (g.Wp + 8) * 2;
+  const dim3 gx(B * (H + 2), lss_cdiv(Cin, 64)), gy(B * (H + 2), lss_cdiv(Cout, 64));
+  hipLaunchKernelGGL(to_channel_major_kernel, gx, dim3(256), lds, st, static_cast<const unsigned short*>(x), B, H,
+                     W, Cin, g.Wp, g.ld, (long long)Cin * g.ld, 3, xt);
+  hipLaunchKernelGGL(to_channel_major_kernel, gy, dim3(256), lds, st, static_cast<const unsigned short*>(dy), B,
+                     H, W, Cout, g.Wp, g.ld, 0LL, 1, dyt);
+  // operand bases skip the lead guard row; tap (ky,kx) then reaches back/forward by one padded row
+  const void* xts[3] = {xt + g.Wp, xt + (size_t)Cin * g.ld + g.Wp, xt + (size_t)2 * Cin * g.ld + g.Wp};
+  int rc = lss_wgrad_gemm_launch(dyt + g.Wp, xts, partial, Cout, Cin, g.ld, g.split_k, g.nsplit, 9, g.Wp, st);
+  if (rc != 0) return rc;
+  const size_t n = (size_t)9 * Cout * Cin;
+  const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, partial, g.nsplit, Cout, Cin, dw_oihw);
+  return lss_launch_status();
+}

@@ -33,6 +33,13 @@ struct LinearArgs {
   int out_f32;
   int group_hw;  // > 0: head-major output (B, N/32, group_hw, 32), rows m = b*group_hw + pixel
   int mtiles, ntiles;
+  long long ldx, ldw;  // row strides of x and w in elements (= K for the plain GEMM)
+  // weight-gradient mode (conv_grad.hip): blockIdx.y = split * ntap + tap.  x = dY^T (Cout rows),
+  // w = one of three column-shifted channel-major copies of the conv input (Cin rows); K = pixels.
+  int ntap;            // 0: plain GEMM
+  long long split_k;   // K elements per split
+  long long tap_row;   // padded image row length: tap (ky, kx) reads copy kx at offset (ky-1)*tap_row
+  const unsigned short* wk[3];
 };
 
 constexpr int BM = 128, BN = 128, BK = 32, NS = 4;
@@ -92,10 +99,22 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(LinearArgs a) {
   }
   const int n0 = (t % a.ntiles) * BN, m0 = (t / a.ntiles) * BM;
   const int wr = wave >> 1, wc = wave & 1;
+  const unsigned short* xbase = a.x;
+  const unsigned short* wbase = a.w;
+  float* ybatch = nullptr;
+  int nsteps = a.K / BK;
+  if (a.ntap > 0) {
+    const int z = blockIdx.y, tap = z % a.ntap, split = z / a.ntap;
+    xbase = a.x + split * a.split_k;
+    wbase = a.wk[tap % 3] + (tap / 3 - 1) * a.tap_row + split * a.split_k;
+    ybatch = reinterpret_cast<float*>(a.y) + (size_t)z * a.M * a.N;
+    nsteps = (int)(a.split_k / BK);
+  }
 
   // DMA: waves 0,1 stage x (blocks 0..7 of 16 rows), waves 2,3 stage w
   const bool is_w = wave >= 2;
-  const unsigned short* gbase = is_w ? a.w : a.x;
+  const unsigned short* gbase = is_w ? wbase : xbase;
+  const long long ld = is_w ? a.ldw : a.ldx;
   const int glim = (is_w ? a.N : a.M) - 1;
   const int g0 = is_w ? n0 : m0;
   size_t goff[4];  // element offset of this lane's 16-B piece at k = 0, per block
@@ -104,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(LinearArgs a) {
     const int blk = (wave & 1) * 4 + i;
     const int row = blk * 16 + (lane >> 2);
     const int piece = (lane & 3) ^ ((row >> 2) & 3);
-    goff[i] = (size_t)min(g0 + row, glim) * a.K + piece * 8;  // rows past the edge re-read the last row
+    goff[i] = (size_t)min(g0 + row, glim) * ld + piece * 8;  // rows past the edge re-read the last row
   }
   const int dma_off = (is_w ? OP_BYTES : 0) + (wave & 1) * 4 * 1024;
   auto issue = [&](int step, int slot) {
@@ -133,7 +152,6 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(LinearArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nsteps = a.K / BK;
   issue(0, 0);
   if (nsteps > 1) issue(1, 1);
   if (nsteps > 2) issue(2, 2);
@@ -200,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(LinearArgs a) {
   }
   lds_barrier();
   unsigned short* yb = reinterpret_cast<unsigned short*>(a.y);
-  float* yf = reinterpret_cast<float*>(a.y);
+  float* yf = ybatch ? ybatch : reinterpret_cast<float*>(a.y);
   const bool vec_ok = (a.N & 7) == 0;
   for (int e = tid; e < BM * (BN / 8); e += 256) {
     const int row = e / (BN / 8), c8 = e % (BN / 8);
@@ -266,10 +284,33 @@ int lss_linear_bf16_launch(const void* x, const void* w, const float* scale, con
   a.residual = static_cast<const unsigned short*>(residual);
   a.y = y;
   a.M = (int)M; a.N = N; a.K = K; a.act = act; a.out_f32 = out_f32; a.group_hw = group_hw;
+  a.ldx = K; a.ldw = K; a.ntap = 0; a.split_k = 0; a.tap_row = 0; a.wk[0] = a.wk[1] = a.wk[2] = nullptr;
   a.mtiles = lss_cdiv(M, BM);
   a.ntiles = lss_cdiv(N, BN);
   const long long nwg = (long long)a.mtiles * a.ntiles;
   if (nwg >= (1LL << 31)) return LSS_E_SHAPE;
   hipLaunchKernelGGL(linear_mfma_kernel, dim3((unsigned)nwg), dim3(256), 0, st, a);
+  return lss_launch_status();
+}
+
+// Internal entry used by lss_conv2d_wgrad (conv_grad.hip): partial[split][tap][M][N] fp32 =
+// sum over the split's K range of dyt[m][k] * xt_kx[n][k + (ky-1)*tap_row].
+int lss_wgrad_gemm_launch(const void* dyt, const void* const xt[3], float* partial, int M, int N,
+                          long long ld, long long split_k, int nsplit, int ntap, long long tap_row,
+                          hipStream_t st) {
+  if (M <= 0 || N <= 0 || split_k <= 0 || split_k % BK != 0 || nsplit <= 0 || ntap <= 0) return LSS_E_SHAPE;
+  LinearArgs a;
+  a.x = static_cast<const unsigned short*>(dyt);
+  a.w = nullptr;
+  a.scale = nullptr; a.shift = nullptr; a.residual = nullptr;
+  a.y = partial;
+  a.M = M; a.N = N; a.K = (int)split_k; a.act = 0; a.out_f32 = 1; a.group_hw = 0;
+  a.mtiles = lss_cdiv(M, BM);
+  a.ntiles = lss_cdiv(N, BN);
+  a.ldx = ld; a.ldw = ld; a.ntap = ntap; a.split_k = split_k; a.tap_row = tap_row;
+  for (int i = 0; i < 3; ++i) a.wk[i] = static_cast<const unsigned short*>(xt[i]);
+  const long long gy = (long long)nsplit * ntap;
+  if (gy > 65535) return LSS_E_SHAPE;
+  hipLaunchKernelGGL(linear_mfma_kernel, dim3((unsigned)(a.mtiles * a.ntiles), (unsigned)gy), dim3(256), 0, st, a);
   return lss_launch_status();
 }

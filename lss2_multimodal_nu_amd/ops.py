@@ -466,6 +466,42 @@ def conv2d_nhwc(x, w_packed, ksize, stride, pad, scale=None, shift=None, residua
     return y.view(B, Cout // 32, Ho * Wo, 32) if head_major else y
 
 
+def pack_conv_weight_dgrad(w_oihw, dt):
+    """OIHW fp32 -> [tap'][Cin][Cout] in dt: the weight of the conv that maps dY to dX
+    (use with conv2d_nhwc(dy, w, (KH,KW), 1, KH-1-pad))."""
+    Cout, Cin, KH, KW = w_oihw.shape
+    _f32c(w_oihw, "conv weight")
+    out = torch.empty(KH * KW, Cin, Cout, dtype=_TORCH_DT[dt], device=w_oihw.device)
+    N.check(N.lib().lss_conv2d_pack_weights_dgrad(N.ptr(w_oihw), Cout, Cin, KH, KW, dt, N.ptr(out), N.stream()),
+            "lss_conv2d_pack_weights_dgrad")
+    return out
+
+
+_wgrad_ws = {}
+
+
+def conv3x3_wgrad(x, dy):
+    """Weight gradient of a 3x3/s1/p1 conv.  x (B,H,W,Cin), dy (B,H,W,Cout) contiguous bf16 NHWC
+    -> dW (Cout,Cin,3,3) fp32.  The workspace is cached per shape and device."""
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    for t, nm in ((x, "x"), (dy, "dy")):
+        if t.dtype != torch.bfloat16 or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError("%s must be a contiguous bf16 NHWC GPU tensor" % nm)
+    if tuple(dy.shape[:3]) != (B, H, W):
+        raise ValueError("dy %s does not match x %s" % (tuple(dy.shape), tuple(x.shape)))
+    nbytes = N.lib().lss_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout)
+    key = (B, H, W, Cin, Cout, str(x.device))
+    ws = _wgrad_ws.get(key)
+    if ws is None:
+        ws = _wgrad_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    dw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=x.device)
+    with _timed("conv2d_wgrad"):
+        N.check(N.lib().lss_conv2d_wgrad(N.ptr(x), N.ptr(dy), B, H, W, Cin, Cout, N.ptr(ws), nbytes, N.ptr(dw),
+                                         N.stream()), "lss_conv2d_wgrad")
+    return dw
+
+
 def pack_conv_weight_s2d(w_oihw, pad):
     """OIHW fp32 of a stride-2 k x k conv -> bf16 [tap'][Cout][4*Cin] for conv2d_s2_nhwc."""
     Cout, Cin, K, K2 = w_oihw.shape
