@@ -281,6 +281,16 @@ size_t lss_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int lss_conv2d_wgrad(const void* x, const void* dy, int B, int H, int W, int Cin, int Cout,
                      void* workspace, size_t workspace_bytes, float* dw_oihw, void* stream);
 
+/* Backward helpers of the fused upsample + concat conv input (ref Up.forward, src/modules.py:22-24;
+ * bf16 NHWC).  lss_upsample_cat_nhwc materialises [x2 | bilinear_align_corners(x, up)] as
+ * (B, H*up, W*up, C2+Cx) - only the weight-gradient GEMM needs it as a tensor.
+ * lss_upsample_bwd_nhwc is the adjoint of the upsample: g = channels [c_off, c_off+Cx) of a
+ * (B, H*up, W*up, Ct) gradient -> dx (B, H, W, Cx); replaces upsample_bilinear2d_backward. */
+int lss_upsample_cat_nhwc(const void* x, const void* x2, int B, int H, int W, int Cx, int C2, int up,
+                          void* out, void* stream);
+int lss_upsample_bwd_nhwc(const void* g, int B, int H, int W, int Cx, int Ct, int c_off, int up,
+                          void* dx, void* stream);
+
 /* Stride-2 convs (3x3 pad 1, 7x7 pad 3, and 1x1 pad 0 with the plain weight pack;
  * bf16) on the LDS-tiled MFMA kernel: the
  * conv is evaluated as a stride-1 conv over the 4 parity phases of the input

@@ -41,6 +41,8 @@ SIGNATURES = {
     "lss_conv2d_pack_weights_dgrad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lss_conv2d_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "lss_conv2d_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "lss_upsample_cat_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "lss_upsample_bwd_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "lss_conv2d_s2d_packed_weight_bytes": (_sz, [_i] * 4),
     "lss_conv2d_pack_weights_s2d": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "lss_conv2d_s2_fwd": (_i, [_vp] * 7 + [_i] * 8 + [_vp]),

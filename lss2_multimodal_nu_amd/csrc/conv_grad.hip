@@ -133,6 +133,96 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+  const unsigned int u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f[2 * k] = lss_bf2f((unsigned short)(u[k] & 0xffff));
+    f[2 * k + 1] = lss_bf2f((unsigned short)(u[k] >> 16));
+  }
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  uint4 o;
+  o.x = lss_pack_bf2(f[0], f[1]); o.y = lss_pack_bf2(f[2], f[3]);
+  o.z = lss_pack_bf2(f[4], f[5]); o.w = lss_pack_bf2(f[6], f[7]);
+  return o;
+}
+
+// out[b, Y, X, :] = [ x2[b, Y, X, :C2] | bilinear_align_corners(x)[b, Y, X, :Cx] ]   (ref Up.forward,
+// src/modules.py:22-24, materialised: only the weight-gradient GEMM needs it as a tensor)
+__global__ __launch_bounds__(256) void upsample_cat_kernel(const unsigned short* __restrict__ x,
+                                                           const unsigned short* __restrict__ x2, int B, int H,
+                                                           int W, int Cx, int C2, int up, float ry, float rx,
+                                                           unsigned short* __restrict__ out) {
+  const int Hh = H * up, Wh = W * up, Ct = C2 + Cx, P8 = Ct / 8;
+  const long long n = (long long)B * Hh * Wh * P8;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int p8 = (int)(e % P8);
+    const long long pix = e / P8;
+    const int X = (int)(pix % Wh), Y = (int)((pix / Wh) % Hh), b = (int)(pix / ((long long)Wh * Hh));
+    const int c = p8 * 8;
+    uint4 o;
+    if (c < C2) {
+      o = *reinterpret_cast<const uint4*>(x2 + (size_t)pix * C2 + c);
+    } else {
+      const float sy = ry * (float)Y, sx = rx * (float)X;
+      const int y0 = (int)sy, x0 = (int)sx;
+      const float ly = sy - (float)y0, lx = sx - (float)x0;
+      const int y1 = y0 < H - 1 ? y0 + 1 : y0, x1 = x0 < W - 1 ? x0 + 1 : x0;
+      const unsigned short* base = x + (size_t)b * H * W * Cx + (c - C2);
+      float a[8], bq[8], cq[8], d[8], r[8];
+      unpack8(*reinterpret_cast<const uint4*>(base + ((size_t)y0 * W + x0) * Cx), a);
+      unpack8(*reinterpret_cast<const uint4*>(base + ((size_t)y0 * W + x1) * Cx), bq);
+      unpack8(*reinterpret_cast<const uint4*>(base + ((size_t)y1 * W + x0) * Cx), cq);
+      unpack8(*reinterpret_cast<const uint4*>(base + ((size_t)y1 * W + x1) * Cx), d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        r[k] = (1.f - ly) * ((1.f - lx) * a[k] + lx * bq[k]) + ly * ((1.f - lx) * cq[k] + lx * d[k]);
+      o = pack8(r);
+    }
+    *reinterpret_cast<uint4*>(out + (size_t)pix * Ct + c) = o;
+  }
+}
+
+// Adjoint of the bilinear (align_corners) upsample, gather form: low-res pixel (y, x) collects
+// from every high-res pixel whose 2x2 source window contains it.  g = channels [c_off, c_off+Cx)
+// of a (B, H*up, W*up, Ct) tensor; dx (B, H, W, Cx).  fp32 accumulation, fixed order.
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const unsigned short* __restrict__ g, int B, int H,
+                                                           int W, int Cx, int Ct, int c_off, int up, float ry,
+                                                           float rx, unsigned short* __restrict__ dx) {
+  const int Hh = H * up, Wh = W * up, P8 = Cx / 8;
+  const long long n = (long long)B * H * W * P8;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int p8 = (int)(e % P8);
+    const long long pix = e / P8;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+    // candidate high-res rows / columns: source coordinate within (y-1, y+1)
+    const int Ylo = max(0, (int)floorf((float)(y - 1) / ry)), Yhi = min(Hh - 1, (int)ceilf((float)(y + 1) / ry));
+    const int Xlo = max(0, (int)floorf((float)(x - 1) / rx)), Xhi = min(Wh - 1, (int)ceilf((float)(x + 1) / rx));
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int Y = Ylo; Y <= Yhi; ++Y) {
+      const float sy = ry * (float)Y;
+      const int y0 = (int)sy;
+      const float ly = sy - (float)y0;
+      const float wy = y0 == y ? 1.f - ly : ((y0 + 1 == y && y0 < H - 1) ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int X = Xlo; X <= Xhi; ++X) {
+        const float sx = rx * (float)X;
+        const int x0 = (int)sx;
+        const float lx = sx - (float)x0;
+        const float wx = x0 == x ? 1.f - lx : ((x0 + 1 == x && x0 < W - 1) ? lx : 0.f);
+        if (wx == 0.f) continue;
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4*>(g + (((size_t)b * Hh + Y) * Wh + X) * Ct + c_off + p8 * 8), v);
+        const float wgt = wy * wx;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = fmaf(wgt, v[k], acc[k]);
+      }
+    }
+    *reinterpret_cast<uint4*>(dx + (size_t)pix * Cx + p8 * 8) = pack8(acc);
+  }
+}
+
 }  // namespace
 
 extern "C" int lss_conv2d_pack_weights_dgrad(const float* w_oihw, int Cout, int Cin, int KH, int KW, int dt,
@@ -199,5 +289,37 @@ extern "C" int lss_conv2d_wgrad(const void* x, const void* dy, int B, int H, int
   const size_t n = (size_t)9 * Cout * Cin;
   const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, partial, g.nsplit, Cout, Cin, dw_oihw);
+  return lss_launch_status();
+}
+
+extern "C" int lss_upsample_cat_nhwc(const void* x, const void* x2, int B, int H, int W, int Cx, int C2, int up,
+                                     void* out, void* stream) {
+  LSS_CHECK_PTR(x); LSS_CHECK_PTR(out);
+  LSS_CHECK_POS(B); LSS_CHECK_POS(H); LSS_CHECK_POS(W); LSS_CHECK_POS(Cx); LSS_CHECK_POS(up);
+  if (C2 < 0 || Cx % 8 != 0 || C2 % 8 != 0) return LSS_E_SHAPE;
+  if (C2 > 0 && x2 == nullptr) return LSS_E_NULL;
+  const int Hh = H * up, Wh = W * up;
+  const float ry = Hh > 1 ? (float)(H - 1) / (float)(Hh - 1) : 0.f, rx = Wh > 1 ? (float)(W - 1) / (float)(Wh - 1) : 0.f;
+  const long long n = (long long)B * Hh * Wh * ((C2 + Cx) / 8);
+  const int grid = (int)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
+  hipLaunchKernelGGL(upsample_cat_kernel, dim3(grid), dim3(256), 0, lss_stream(stream),
+                     static_cast<const unsigned short*>(x), static_cast<const unsigned short*>(x2), B, H, W, Cx, C2,
+                     up, ry, rx, static_cast<unsigned short*>(out));
+  return lss_launch_status();
+}
+
+extern "C" int lss_upsample_bwd_nhwc(const void* g, int B, int H, int W, int Cx, int Ct, int c_off, int up,
+                                     void* dx, void* stream) {
+  LSS_CHECK_PTR(g); LSS_CHECK_PTR(dx);
+  LSS_CHECK_POS(B); LSS_CHECK_POS(H); LSS_CHECK_POS(W); LSS_CHECK_POS(Cx); LSS_CHECK_POS(up);
+  if (c_off < 0 || Cx % 8 != 0 || c_off % 8 != 0 || c_off + Cx > Ct || Ct % 8 != 0) return LSS_E_SHAPE;
+  const int Hh = H * up, Wh = W * up;
+  const float ry = Hh > 1 ? (float)(H - 1) / (float)(Hh - 1) : 0.f, rx = Wh > 1 ? (float)(W - 1) / (float)(Wh - 1) : 0.f;
+  if (H < 2 || W < 2) return LSS_E_SHAPE;  // ry, rx > 0 below
+  const long long n = (long long)B * H * W * (Cx / 8);
+  const int grid = (int)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid), dim3(256), 0, lss_stream(stream),
+                     static_cast<const unsigned short*>(g), B, H, W, Cx, Ct, c_off, up, ry, rx,
+                     static_cast<unsigned short*>(dx));
   return lss_launch_status();
 }

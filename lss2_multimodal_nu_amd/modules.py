@@ -39,6 +39,110 @@ def _needs_autograd(module, *inputs):
         or any(p.requires_grad for p in module.parameters())
 
 
+class _Conv3x3Fn(torch.autograd.Function):
+    """Bias-free 3x3 / stride 1 / pad 1 conv with BOTH directions on the HIP kernels: forward = K8,
+    input gradient = K8 on the flipped/transposed weight pack, weight gradient = split-K MFMA GEMM
+    over channel-major copies (csrc/conv_grad.hip).  Takes / returns logical (B,C,H,W) tensors; the
+    arithmetic is bf16 NHWC with fp32 accumulation, the weight gradient fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        xn = x.permute(0, 2, 3, 1)
+        if xn.dtype != torch.bfloat16:
+            xn = xn.to(torch.bfloat16)
+        xn = xn.contiguous()  # no copy when x is already channels_last
+        wp = ops.pack_conv_weight(weight.detach().float().contiguous(), ops.DT_BF16)
+        y = ops.conv2d_nhwc(xn, wp, (3, 3), 1, 1, tag="conv2d_train_fwd")
+        ctx.save_for_backward(xn, weight)
+        ctx.x_dtype = x.dtype
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xn, weight = ctx.saved_tensors
+        gyn = gy.permute(0, 2, 3, 1)
+        if gyn.dtype != torch.bfloat16:
+            gyn = gyn.to(torch.bfloat16)
+        gyn = gyn.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            wd = ops.pack_conv_weight_dgrad(weight.detach().float().contiguous(), ops.DT_BF16)
+            gx = ops.conv2d_nhwc(gyn, wd, (3, 3), 1, 1, tag="conv2d_dgrad").permute(0, 3, 1, 2).to(ctx.x_dtype)
+        if ctx.needs_input_grad[1]:
+            gw = ops.conv3x3_wgrad(xn, gyn).to(weight.dtype)
+        return gx, gw
+
+
+class _UpConv3x3Fn(torch.autograd.Function):
+    """conv3x3(cat([x2, bilinear_align_corners(x1, up)])) with the upsample and the concat fused into
+    the conv's operand gather in the forward (neither tensor exists), and in the backward: one dgrad
+    conv for the concatenated input, the upsample's adjoint as a gather kernel, and the concatenated
+    input re-materialised in bf16 only for the weight-gradient GEMM.  x2 may be None (plain upsample)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, up):
+        def nhwc(t):
+            t = t.permute(0, 2, 3, 1)
+            return (t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)).contiguous()
+
+        x1n = nhwc(x1)
+        x2n = None if x2 is None else nhwc(x2)
+        wp = ops.pack_conv_weight(weight.detach().float().contiguous(), ops.DT_BF16)
+        y = ops.conv2d_nhwc(x1n, wp, (3, 3), 1, 1, x2=x2n, up=up, tag="conv2d_train_fwd")
+        ctx.save_for_backward(x1n, x2n, weight)
+        ctx.up = up
+        ctx.dtypes = (x1.dtype, None if x2 is None else x2.dtype)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x1n, x2n, weight = ctx.saved_tensors
+        up = ctx.up
+        C2 = 0 if x2n is None else x2n.shape[3]
+        Cx = x1n.shape[3]
+        gyn = gy.permute(0, 2, 3, 1)
+        gyn = (gyn if gyn.dtype == torch.bfloat16 else gyn.to(torch.bfloat16)).contiguous()
+        g1 = g2 = gw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            wd = ops.pack_conv_weight_dgrad(weight.detach().float().contiguous(), ops.DT_BF16)
+            gcat = ops.conv2d_nhwc(gyn, wd, (3, 3), 1, 1, tag="conv2d_dgrad")  # (B, H*up, W*up, C2+Cx)
+            if ctx.needs_input_grad[0]:
+                g1 = ops.upsample_bwd_nhwc(gcat, C2, Cx, up).permute(0, 3, 1, 2).to(ctx.dtypes[0])
+            if x2n is not None and ctx.needs_input_grad[1]:
+                g2 = gcat[..., :C2].permute(0, 3, 1, 2).to(ctx.dtypes[1])
+        if ctx.needs_input_grad[2]:
+            gw = ops.conv3x3_wgrad(ops.upsample_cat_nhwc(x1n, x2n, up), gyn).to(weight.dtype)
+        return g1, g2, gw, None
+
+
+def _native_training():
+    """Training convs go to the HIP kernels when the caller asked for bf16 math (bf16 autocast);
+    plain fp32 training keeps torch's fp32 convolutions.  LSS_TRAIN_NATIVE=0 disables."""
+    return (os.environ.get("LSS_TRAIN_NATIVE", "1") != "0" and torch.is_autocast_enabled("cuda")
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
+
+def _train_up_conv(conv, up, x1, x2):
+    """conv(cat([x2, upsample(x1)])) on the autograd path (x2 may be None)."""
+    c2 = 0 if x2 is None else x2.shape[1]
+    if (x1.is_cuda and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.bias is None and x1.shape[1] % 64 == 0 and c2 % 64 == 0 and conv.out_channels % 8 == 0
+            and x1.shape[2] > 1 and x1.shape[3] > 1 and _native_training()):
+        return _UpConv3x3Fn.apply(x1, x2, conv.weight, int(up.scale_factor))
+    x1 = up(x1)
+    return _train_conv(conv, x1 if x2 is None else torch.cat([x2, x1], dim=1))
+
+
+def _train_conv(conv, x):
+    """conv(x) on the autograd path: the 3x3/s1/p1 shapes (95 % of BevEncode's FLOPs) run
+    forward and backward on the HIP kernels, everything else on the library."""
+    if (x.is_cuda and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+            and conv.in_channels % 64 == 0 and conv.out_channels % 8 == 0 and _native_training()):
+        return _Conv3x3Fn.apply(x, conv.weight)
+    return conv(x)
+
+
 class _FoldedConv:
     """Packed weights + eval-mode BatchNorm folded into (scale, shift) for one
     conv of the HIP path; rebuilt only when a source tensor changes."""
@@ -156,8 +260,9 @@ class Up(nn.Module):
 
     def forward(self, x1, x2):
         if _needs_autograd(self, x1, x2):
-            x1 = self.up(x1)
-            return self.conv(torch.cat([x2, x1], dim=1))
+            c = self.conv
+            y = c[2](c[1](_train_up_conv(c[0], self.up, x1, x2)))
+            return c[5](c[4](_train_conv(c[3], y)))
         dt = _PRECISIONS[self.precision or default_precision()]
         y = self._nhwc(_to_nhwc(x1, dt), _to_nhwc(x2, dt), dt)
         return ops.nhwc_to_nchw(y, dt)
@@ -254,8 +359,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
+        out = self.relu(self.bn1(_train_conv(self.conv1, x)))
+        out = self.bn2(_train_conv(self.conv2, out))
         return self.relu(out + idt)
 
     def _nhwc(self, x, dt):
@@ -307,11 +412,14 @@ class BevEncode(nn.Module):
         self._up2b = _FoldedConv(self.up2[4], None)
 
     def _forward_autograd(self, x):
+        if _native_training() and x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)  # the whole chain then stays NHWC
         x = self.relu(self.bn1(self.conv1(x)))
         x1 = self.layer1(x)
         x = self.layer3(self.layer2(x1))
         x = self.up1(x, x1)
-        return self.up2(x)
+        u = self.up2
+        return u[4](u[3](u[2](_train_up_conv(u[1], u[0], x, None)))).float()
 
     def invalidate_plan(self):
         """Drop the cached launch lists (called whenever parameters may have changed)."""

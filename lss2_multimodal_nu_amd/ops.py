@@ -502,6 +502,35 @@ def conv3x3_wgrad(x, dy):
     return dw
 
 
+def upsample_cat_nhwc(x, x2, up):
+    """[x2 | bilinear_align_corners(x, up)] as a contiguous bf16 (B, H*up, W*up, C2+Cx) tensor."""
+    B, H, W, Cx = x.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    for t in (x, x2):
+        if t is not None and (t.dtype != torch.bfloat16 or not t.is_contiguous()):
+            raise ValueError("upsample_cat_nhwc operands must be contiguous bf16 NHWC")
+    if x2 is not None and tuple(x2.shape[:3]) != (B, H * up, W * up):
+        raise ValueError("x2 %s does not match x %s upsampled x%d" % (tuple(x2.shape), tuple(x.shape), up))
+    out = torch.empty(B, H * up, W * up, C2 + Cx, dtype=torch.bfloat16, device=x.device)
+    with _timed("upsample_cat"):
+        N.check(N.lib().lss_upsample_cat_nhwc(N.ptr(x), N.ptr(x2), B, H, W, Cx, C2, up, N.ptr(out), N.stream()),
+                "lss_upsample_cat_nhwc")
+    return out
+
+
+def upsample_bwd_nhwc(g, c_off, Cx, up):
+    """Adjoint of the bilinear (align_corners) x`up` upsample applied to channels [c_off, c_off+Cx)
+    of g (B, H*up, W*up, Ct) bf16 -> (B, H, W, Cx) bf16."""
+    B, Hh, Wh, Ct = g.shape
+    if g.dtype != torch.bfloat16 or not g.is_contiguous() or Hh % up or Wh % up:
+        raise ValueError("g must be contiguous bf16 NHWC with sizes divisible by the scale")
+    dx = torch.empty(B, Hh // up, Wh // up, Cx, dtype=torch.bfloat16, device=g.device)
+    with _timed("upsample_bwd"):
+        N.check(N.lib().lss_upsample_bwd_nhwc(N.ptr(g), B, Hh // up, Wh // up, Cx, Ct, c_off, up, N.ptr(dx),
+                                              N.stream()), "lss_upsample_bwd_nhwc")
+    return dx
+
+
 def pack_conv_weight_s2d(w_oihw, pad):
     """OIHW fp32 of a stride-2 k x k conv -> bf16 [tap'][Cout][4*Cin] for conv2d_s2_nhwc."""
     Cout, Cin, K, K2 = w_oihw.shape

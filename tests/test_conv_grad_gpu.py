@@ -59,3 +59,58 @@ def test_wgrad_argument_checks():
         ops.conv3x3_wgrad(x.float(), x)
     with pytest.raises(ValueError):
         ops.conv3x3_wgrad(x, torch.zeros(1, 4, 5, 64).bfloat16().cuda())
+
+
+def test_bevencode_training_native_convs_match_library(monkeypatch):
+    """bf16-autocast training step of BevEncode: HIP fwd/dgrad/wgrad convs vs the library's convs."""
+    import lss2_multimodal_nu_amd as L
+    torch.manual_seed(3)
+    be = L.BevEncode(64, 4).cuda().train()
+    x0 = torch.randn(2, 64, 96, 80, device="cuda")
+    tgt = torch.randn(2, 4, 96, 80, device="cuda")
+
+    def run(native):
+        monkeypatch.setenv("LSS_TRAIN_NATIVE", "1" if native else "0")
+        be.zero_grad(set_to_none=True)
+        for m in be.modules():  # same batch statistics start for both runs
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        x = x0.clone().requires_grad_(True)
+        spans = ops.KernelTimer(fine=True)
+        ops.set_timer(spans)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = be(x)
+        loss = ((y.float() - tgt) ** 2).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        ops.set_timer(None)
+        grads = {n: p.grad.detach().float().clone() for n, p in be.named_parameters()}
+        return y.detach().float(), x.grad.detach().clone(), grads, set(spans.spans)
+
+    y_n, gx_n, g_n, tags = run(True)
+    y_l, gx_l, g_l, tags_l = run(False)
+    assert {"conv2d_train_fwd", "conv2d_dgrad", "conv2d_wgrad", "upsample_bwd", "upsample_cat"} <= tags and not tags_l  # the HIP kernels really ran
+    cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm() + 1e-30))  # noqa: E731
+    assert cos(y_n, y_l) > 0.999 and cos(gx_n, gx_l) > 0.995
+    for n in g_n:
+        if g_l[n].norm() > 0:
+            assert cos(g_n[n], g_l[n]) > 0.99, (n, cos(g_n[n], g_l[n]))
+
+
+@pytest.mark.parametrize("up,C2", [(2, 0), (4, 64), (2, 128)])
+def test_upsample_cat_and_adjoint_vs_torch(up, C2):
+    g = torch.Generator().manual_seed(up * 10 + C2)
+    B, H, W, Cx = 2, 7, 9, 64
+    x = torch.randn(B, H, W, Cx, generator=g).bfloat16()
+    x2 = torch.randn(B, H * up, W * up, C2, generator=g).bfloat16() if C2 else None
+    cat = ops.upsample_cat_nhwc(x.cuda(), None if x2 is None else x2.cuda(), up)
+    xf = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    upx = torch.nn.functional.interpolate(xf, scale_factor=up, mode="bilinear", align_corners=True)
+    ref = upx if x2 is None else torch.cat([x2.float().permute(0, 3, 1, 2), upx], 1)
+    err = float((cat.float().cpu().permute(0, 3, 1, 2) - ref).abs().max())
+    assert err <= 2e-2  # bf16 rounding of the blend
+    gcat = torch.randn(B, H * up, W * up, C2 + Cx, generator=g).bfloat16()
+    dx = ops.upsample_bwd_nhwc(gcat.cuda(), C2, Cx, up)
+    upx.backward(gcat.float()[..., C2:].permute(0, 3, 1, 2))
+    ref_dx = xf.grad.permute(0, 2, 3, 1)
+    assert float((dx.float().cpu() - ref_dx).abs().max()) <= 1e-2 * float(ref_dx.abs().max())

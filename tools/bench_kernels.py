@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel micro-benchmark on one GPU: every BevEncode conv shape at batch B
 (bf16) and the L1 kernels, timed with HIP events on the launch stream.
-    python tools/bench_kernels.py [--batch 4] [--iters 30] [--only conv|l1|vovnet|gemm]
+    python tools/bench_kernels.py [--batch 4] [--iters 30] [--only conv|l1|vovnet|gemm|grad]
 `--only vovnet` times BASELINE configs[3] (vovnet shapes, C=128, BEV transformer) stage by stage."""
 import argparse
 import os
@@ -111,6 +111,26 @@ def main():
         vovnet(args)
     if args.only == "gemm":
         gemm(args)
+    if args.only == "grad":
+        grad(args)
+
+
+def grad(args):
+    """dgrad / wgrad of the 3x3 convs at the bench batch (bf16), against the forward kernel."""
+    B = args.batch
+    print("%-18s %10s %10s %10s   (us; TF/s in brackets)" % ("conv 3x3 (B=%d)" % B, "fwd", "dgrad", "wgrad"))
+    for name, H, W, Cin, Cout in [("layer1", 100, 100, 64, 64), ("layer2", 50, 50, 128, 128), ("layer3", 25, 25, 256, 256),
+                                  ("up1.conv0", 100, 100, 320, 256), ("up1.conv3", 100, 100, 256, 256),
+                                  ("up2.1", 200, 200, 256, 128)]:
+        x = torch.randn(B, H, W, Cin, device="cuda").to(torch.bfloat16)
+        dy = torch.randn(B, H, W, Cout, device="cuda").to(torch.bfloat16)
+        w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
+        wf, wd = ops.pack_conv_weight(w, ops.DT_BF16), ops.pack_conv_weight_dgrad(w, ops.DT_BF16)
+        fl = 2.0 * B * H * W * Cin * Cout * 9
+        tf = timeit(lambda: ops.conv2d_nhwc(x, wf, (3, 3), 1, 1), args.iters)
+        td = timeit(lambda: ops.conv2d_nhwc(dy, wd, (3, 3), 1, 1), args.iters)
+        tw = timeit(lambda: ops.conv3x3_wgrad(x, dy), args.iters)
+        print("%-18s %6.1f [%4.0f] %6.1f [%4.0f] %6.1f [%4.0f]" % (name, tf, fl / tf / 1e6, td, fl / td / 1e6, tw, fl / tw / 1e6))
 
 
 def gemm(args):
