@@ -291,6 +291,50 @@ int lss_upsample_cat_nhwc(const void* x, const void* x2, int B, int H, int W, in
 int lss_upsample_bwd_nhwc(const void* g, int B, int H, int W, int Cx, int Ct, int c_off, int up,
                           void* dx, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Training-mode BatchNorm2d (+ residual + ReLU) over NHWC bf16 rows, forward and backward.
+ * replaces: batch_norm / add / relu (and their autograd nodes) of src/modules.py:16-21,
+ *           100-101, 112-113 and torchvision BasicBlock.forward under model.train().
+ *   z (M, C) bf16 raw conv output, M = B*H*W; residual (M, C) bf16 or NULL
+ *   y = act(gamma * (z - mean) * invstd + beta (+ residual)), bf16
+ *   running_mean/var (C) fp32 updated in place with `momentum` (both NULL: not tracked);
+ *   save_mean, save_invstd (C) fp32 out - the batch statistics the backward needs
+ *   workspace: lss_bn_train_workspace_bytes(M, C) bytes (partial sums; reusable between calls)
+ * Backward: dz (M, C) bf16 = gradient w.r.t. z; dres (M, C) bf16 or NULL = gradient w.r.t.
+ *   residual (= dy masked by the ReLU); dgamma, dbeta (C) fp32, overwritten.
+ * C % 8 == 0, 256 % (C/8) == 0.  Fixed summation order: bit-reproducible.
+ */
+size_t lss_bn_train_workspace_bytes(long long M, int C);
+int lss_bn_train_fwd(const void* z, const void* residual, long long M, int C, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float momentum,
+                     float eps, int relu, void* workspace, void* y, float* save_mean,
+                     float* save_invstd, void* stream);
+int lss_bn_train_bwd(const void* dy, const void* y, const void* z, long long M, int C,
+                     const float* gamma, const float* save_mean, const float* save_invstd, int relu,
+                     void* workspace, void* dz, void* dres, float* dgamma, float* dbeta, void* stream);
+
+/* One-call training units (the training step is framework-bound: chaining the launches here costs
+ * two host calls per conv+BN unit instead of sixteen).
+ * forward:  z = conv3x3(x) with x = x1 (up = 1, C2 = 0) or cat([x2, bilinear_align_corners(x1, up)]),
+ *           y = act(BN_train(z) (+ residual));  w_packed: scratch of 9*Cout*(Cx+C2) bf16.
+ * backward: BN backward -> dz (and dres); if gcat != NULL: gcat = dgrad conv (B,H*up,W*up,Cx+C2) bf16
+ *           (w_dgrad: scratch like w_packed), and if g1 != NULL: g1 = upsample adjoint of gcat's
+ *           channels [C2, C2+Cx) -> (B,H,W,Cx); if dw != NULL: dw (Cout,Cx+C2,3,3) fp32 via
+ *           lss_conv2d_wgrad (xcat: scratch (B,H*up,W*up,Cx+C2) bf16 when up > 1 or C2 > 0).
+ * All tensors bf16 NHWC unless noted; shapes/limits as the individual entry points. */
+int lss_conv_bn_act_train_fwd(const void* x1, const void* x2, const float* w_oihw, const float* gamma,
+                              const float* beta, const void* residual, float* running_mean,
+                              float* running_var, void* w_packed, void* z, void* y, float* save_mean,
+                              float* save_invstd, void* bn_workspace, int B, int H, int W, int Cx, int C2,
+                              int up, int Cout, float momentum, float eps, int relu, void* stream);
+int lss_conv_bn_act_train_bwd(const void* dy, const void* y, const void* z, const void* x1, const void* x2,
+                              const float* w_oihw, const float* gamma, const float* save_mean,
+                              const float* save_invstd, void* bn_workspace, void* wgrad_workspace,
+                              size_t wgrad_workspace_bytes, void* w_dgrad, void* dz, void* dres,
+                              float* dgamma, float* dbeta, void* gcat, void* g1, void* xcat, float* dw,
+                              int B, int H, int W, int Cx, int C2, int up, int Cout, int relu,
+                              void* stream);
+
 /* Stride-2 convs (3x3 pad 1, 7x7 pad 3, and 1x1 pad 0 with the plain weight pack;
  * bf16) on the LDS-tiled MFMA kernel: the
  * conv is evaluated as a stride-1 conv over the 4 parity phases of the input

@@ -27,6 +27,7 @@ SOURCES = {
     "bev_transformer.hip": [],
     "linear_mfma.hip": [],
     "conv_grad.hip": [],
+    "bn_train.hip": [],
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-variable",
           "-Wno-unused-but-set-variable"]

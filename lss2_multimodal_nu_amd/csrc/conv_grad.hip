@@ -98,6 +98,21 @@ __global__ __launch_bounds__(256) void to_channel_major_kernel(const unsigned sh
     }
   }
   __syncthreads();
+  // the first / last workgroup of a channel block also clears the lead guard row and everything
+  // past the image grid (K tail + tail guard row) of its rows: no separate memset launches
+  if (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) {
+    const long long kimg = (long long)B * (H + 2) * Wp;
+    const long long lo = blockIdx.x == 0 ? 0 : Wp + kimg, hi = blockIdx.x == 0 ? Wp : ld;
+    const long long n8 = (hi - lo) / 8;
+    for (long long e = tid; e < (long long)ncopy * 64 * n8; e += 256) {
+      const long long ch = e % n8;
+      const int c = (int)((e / n8) % 64);
+      const int copy = (int)(e / (n8 * 64));
+      if (c0 + c < C)
+        *reinterpret_cast<uint4*>(dst + (size_t)copy * copy_stride + (size_t)(c0 + c) * ld + lo + ch * 8) =
+            make_uint4(0, 0, 0, 0);
+    }
+  }
   const long long flat0 = ((long long)b * (H + 2) + yp) * Wp + Wp;  // + Wp: the lead guard row
   const int chunks = Wp / 8;
   for (int e = tid; e < ncopy * 64 * chunks; e += 256) {
@@ -264,18 +279,6 @@ extern "C" int lss_conv2d_wgrad(const void* x, const void* dy, int B, int H, int
   unsigned short* dyt = reinterpret_cast<unsigned short*>(ws + xt_bytes);
   const size_t dyt_bytes = align256((size_t)Cout * g.ld * 2);
   float* partial = reinterpret_cast<float*>(ws + xt_bytes + dyt_bytes);
-  // the lead guard row and everything past the image grid (K tail + tail guard row) must read
-  // as zeros; the grid itself (borders included) is rewritten below
-  const long long kimg = (long long)B * (H + 2) * g.Wp;
-  const size_t pitch = (size_t)g.ld * 2;
-  for (int which = 0; which < 2; ++which) {
-    unsigned char* base = which == 0 ? reinterpret_cast<unsigned char*>(xt) : reinterpret_cast<unsigned char*>(dyt);
-    const size_t rows = which == 0 ? (size_t)3 * Cin : (size_t)Cout;
-    hipError_t e = hipMemset2DAsync(base, pitch, 0, (size_t)g.Wp * 2, rows, st);
-    if (e == hipSuccess)
-      e = hipMemset2DAsync(base + ((size_t)g.Wp + kimg) * 2, pitch, 0, (size_t)(g.ld - g.Wp - kimg) * 2, rows, st);
-    if (e != hipSuccess) return (int)e;
-  }
   const size_t lds = (size_t)64 * (g.Wp + 8) * 2;
   const dim3 gx(B * (H + 2), lss_cdiv(Cin, 64)), gy(B * (H + 2), lss_cdiv(Cout, 64));
   hipLaunchKernelGGL(to_channel_major_kernel, gx, dim3(256), lds, st, static_cast<const unsigned short*>(x), B, H,

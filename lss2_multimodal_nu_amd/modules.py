@@ -115,6 +115,125 @@ class _UpConv3x3Fn(torch.autograd.Function):
         return g1, g2, gw, None
 
 
+class _BNActFn(torch.autograd.Function):
+    """Training-mode BatchNorm2d (+ residual add, + ReLU) on the HIP kernels (csrc/bn_train.hip),
+    forward and backward; logical (B,C,H,W) tensors in, computed on bf16 NHWC rows.  Running
+    statistics are updated in place like nn.BatchNorm2d (momentum must be a number)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, residual, running_mean, running_var, momentum, eps, relu):
+        def nhwc(t):
+            t = t.permute(0, 2, 3, 1)
+            return (t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)).contiguous()
+
+        zn = nhwc(z)
+        rn = None if residual is None else nhwc(residual)
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        y, mean, invstd = ops.bn_train_fwd(zn, g32, b32, running_mean, running_var, momentum, eps, relu, rn)
+        ctx.save_for_backward(zn, y, g32, mean, invstd)
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        ctx.dtypes = (z.dtype, None if residual is None else residual.dtype, gamma.dtype)
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var) if t is not None])
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        zn, y, g32, mean, invstd = ctx.saved_tensors
+        gyn = gy.permute(0, 2, 3, 1)
+        gyn = (gyn if gyn.dtype == torch.bfloat16 else gyn.to(torch.bfloat16)).contiguous()
+        want_res = ctx.has_res and ctx.needs_input_grad[3]
+        dz, dres, dgamma, dbeta = ops.bn_train_bwd(gyn, y, zn, g32, mean, invstd, ctx.relu, want_res)
+        gz = dz.permute(0, 3, 1, 2).to(ctx.dtypes[0]) if ctx.needs_input_grad[0] else None
+        gres = dres.permute(0, 3, 1, 2).to(ctx.dtypes[1]) if want_res else None
+        return (gz, dgamma.to(ctx.dtypes[2]) if ctx.needs_input_grad[1] else None,
+                dbeta.to(ctx.dtypes[2]) if ctx.needs_input_grad[2] else None, gres, None, None, None, None, None)
+
+
+def _nhwc_bf16(t):
+    t = t.permute(0, 2, 3, 1)
+    if t.dtype != torch.bfloat16:
+        t = t.to(torch.bfloat16)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _ConvBNActFn(torch.autograd.Function):
+    """One autograd node for a whole `conv3x3 -> BatchNorm(train) -> (+residual) -> ReLU` unit, with the
+    optional fused `cat([x2, upsample(x1)])` input: conv forward / dgrad / wgrad, BN forward /
+    backward and the upsample adjoint all on the HIP kernels.  One node instead of three keeps the
+    Python/autograd overhead per layer below the kernels' own time (the training step is otherwise
+    host-bound: ~340 us of framework time per conv+BN unit)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, up):
+        x1n = _nhwc_bf16(x1)
+        x2n = None if x2 is None else _nhwc_bf16(x2)
+        rn = None if residual is None else _nhwc_bf16(residual)
+        w, g32 = weight.detach(), gamma.detach()
+        z, y, stat = ops.conv_bn_act_train_fwd(x1n, x2n, w, g32, beta.detach(), rn, running_mean, running_var,
+                                               momentum, eps, relu, up)
+        ctx.save_for_backward(x1n, x2n, z, y, w, g32, stat)
+        ctx.cfg = (relu, up, residual is not None, x1.dtype, None if x2 is None else x2.dtype,
+                   None if residual is None else residual.dtype)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x1n, x2n, z, y, w, g32, stat = ctx.saved_tensors
+        relu, up, has_res, dt1, dt2, dtr = ctx.cfg
+        need = ctx.needs_input_grad
+        g1, g2, gw, dgamma, dbeta, dres = ops.conv_bn_act_train_bwd(
+            _nhwc_bf16(gy), y, z, x1n, x2n, w, g32, stat, relu, up, has_res and need[5], need[0],
+            x2n is not None and need[1], need[2])
+
+        def out(t, dt):
+            if t is None:
+                return None
+            t = t.permute(0, 3, 1, 2)
+            return t if t.dtype == dt else t.to(dt)
+
+        return (out(g1, dt1), out(g2, dt2), gw, dgamma if need[3] else None, dbeta if need[4] else None,
+                out(dres, dtr), None, None, None, None, None, None)
+
+
+def _bn_native_ok(bn, z_is_cuda):
+    C = bn.num_features
+    return (z_is_cuda and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
+            and C % 8 == 0 and 256 % (C // 8) == 0 and bn.weight.dtype == torch.float32)
+
+
+def _train_conv_bn_act(conv, bn, x1, relu, residual=None, up=None, x2=None):
+    """act(bn(conv(x)) (+ residual)) on the autograd path, x = x1 or cat([x2, up(x1)]).  One fused
+    HIP node when the shapes allow and the caller asked for bf16 math; otherwise composed from
+    the separate (native or library) pieces."""
+    c2 = 0 if x2 is None else x2.shape[1]
+    scale = 1 if up is None else int(up.scale_factor)
+    if (x1.is_cuda and _native_training() and _bn_native_ok(bn, True) and conv.kernel_size == (3, 3)
+            and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.bias is None and conv.weight.dtype == torch.float32 and x1.shape[1] % 64 == 0 and c2 % 64 == 0
+            and conv.out_channels % 8 == 0 and (scale == 1 or (x1.shape[2] > 1 and x1.shape[3] > 1))):
+        y = _ConvBNActFn.apply(x1, x2, conv.weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
+                               float(bn.momentum), float(bn.eps), bool(relu), scale)
+        bn.num_batches_tracked.add_(1)
+        return y
+    z = _train_conv(conv, x1) if up is None else _train_up_conv(conv, up, x1, x2)
+    return _train_bn_act(bn, z, relu, residual)
+
+
+def _train_bn_act(bn, z, relu, residual=None):
+    """act(bn(z) (+ residual)) on the autograd path: one fused HIP forward/backward pair when the
+    caller asked for bf16 math and the module is in training mode, the library ops otherwise."""
+    if _native_training() and _bn_native_ok(bn, z.is_cuda):
+        y = _BNActFn.apply(z, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, float(bn.momentum),
+                           float(bn.eps), bool(relu))
+        bn.num_batches_tracked.add_(1)
+        return y
+    y = bn(z)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
 def _native_training():
     """Training convs go to the HIP kernels when the caller asked for bf16 math (bf16 autocast);
     plain fp32 training keeps torch's fp32 convolutions.  LSS_TRAIN_NATIVE=0 disables."""
@@ -261,8 +380,8 @@ class Up(nn.Module):
     def forward(self, x1, x2):
         if _needs_autograd(self, x1, x2):
             c = self.conv
-            y = c[2](c[1](_train_up_conv(c[0], self.up, x1, x2)))
-            return c[5](c[4](_train_conv(c[3], y)))
+            y = _train_conv_bn_act(c[0], c[1], x1, relu=True, up=self.up, x2=x2)
+            return _train_conv_bn_act(c[3], c[4], y, relu=True)
         dt = _PRECISIONS[self.precision or default_precision()]
         y = self._nhwc(_to_nhwc(x1, dt), _to_nhwc(x2, dt), dt)
         return ops.nhwc_to_nchw(y, dt)
@@ -358,10 +477,9 @@ class BasicBlock(nn.Module):
         self._fd = _FoldedConv(self.downsample[0], self.downsample[1]) if self.downsample is not None else None
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(_train_conv(self.conv1, x)))
-        out = self.bn2(_train_conv(self.conv2, out))
-        return self.relu(out + idt)
+        idt = x if self.downsample is None else _train_bn_act(self.downsample[1], self.downsample[0](x), relu=False)
+        out = _train_conv_bn_act(self.conv1, self.bn1, x, relu=True)
+        return _train_conv_bn_act(self.conv2, self.bn2, out, relu=True, residual=idt)
 
     def _nhwc(self, x, dt):
         idt = x if self._fd is None else self._fd.run(x, dt, relu=False)
@@ -414,12 +532,12 @@ class BevEncode(nn.Module):
     def _forward_autograd(self, x):
         if _native_training() and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)  # the whole chain then stays NHWC
-        x = self.relu(self.bn1(self.conv1(x)))
+        x = _train_bn_act(self.bn1, self.conv1(x), relu=True)
         x1 = self.layer1(x)
         x = self.layer3(self.layer2(x1))
         x = self.up1(x, x1)
         u = self.up2
-        return u[4](u[3](u[2](_train_up_conv(u[1], u[0], x, None)))).float()
+        return u[4](_train_conv_bn_act(u[1], u[2], x, relu=True, up=u[0])).float()
 
     def invalidate_plan(self):
         """Drop the cached launch lists (called whenever parameters may have changed)."""

@@ -531,6 +531,128 @@ def upsample_bwd_nhwc(g, c_off, Cx, up):
     return dx
 
 
+_bn_ws = {}
+
+
+def _bn_workspace(M, C, device):
+    key = (M, C, str(device))
+    ws = _bn_ws.get(key)
+    if ws is None:
+        nbytes = N.lib().lss_bn_train_workspace_bytes(M, C)
+        if nbytes == 0:
+            raise ValueError("BatchNorm over %d rows x %d channels is outside the kernels' range" % (M, C))
+        ws = _bn_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
+def bn_train_fwd(z, gamma, beta, running_mean, running_var, momentum, eps, relu, residual=None):
+    """Training-mode BatchNorm (+residual, +ReLU) on contiguous bf16 NHWC z (..., C).
+    Returns y (bf16, like z), save_mean, save_invstd (fp32); running stats updated in place."""
+    C = z.shape[-1]
+    M = z.numel() // C
+    for t, nm in ((z, "z"), (residual, "residual")):
+        if t is not None and (t.dtype != torch.bfloat16 or not t.is_contiguous() or tuple(t.shape) != tuple(z.shape)):
+            raise ValueError("%s must be contiguous bf16 shaped like z" % nm)
+    _f32c(gamma, "gamma", (C,))
+    _f32c(beta, "beta", (C,))
+    if running_mean is not None:
+        _f32c(running_mean, "running_mean", (C,))
+        _f32c(running_var, "running_var", (C,))
+    y = torch.empty_like(z)
+    mean = torch.empty(C, dtype=torch.float32, device=z.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=z.device)
+    with _timed("bn_train_fwd"):
+        N.check(N.lib().lss_bn_train_fwd(N.ptr(z), N.ptr(residual), M, C, N.ptr(gamma), N.ptr(beta), N.ptr(running_mean),
+                                         N.ptr(running_var), float(momentum), float(eps), 1 if relu else 0,
+                                         N.ptr(_bn_workspace(M, C, z.device)), N.ptr(y), N.ptr(mean), N.ptr(invstd),
+                                         N.stream()), "lss_bn_train_fwd")
+    return y, mean, invstd
+
+
+def bn_train_bwd(dy, y, z, gamma, mean, invstd, relu, want_dres):
+    """Backward of bn_train_fwd: returns dz (bf16), dres (bf16 or None), dgamma, dbeta (fp32)."""
+    C = z.shape[-1]
+    M = z.numel() // C
+    for t, nm in ((dy, "dy"), (z, "z"), (y, "y")):
+        if t is not None and (t.dtype != torch.bfloat16 or not t.is_contiguous() or tuple(t.shape) != tuple(z.shape)):
+            raise ValueError("%s must be contiguous bf16 shaped like z" % nm)
+    dz = torch.empty_like(z)
+    dres = torch.empty_like(z) if want_dres else None
+    dgamma = torch.empty(C, dtype=torch.float32, device=z.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=z.device)
+    with _timed("bn_train_bwd"):
+        N.check(N.lib().lss_bn_train_bwd(N.ptr(dy), N.ptr(y), N.ptr(z), M, C, N.ptr(gamma), N.ptr(mean), N.ptr(invstd),
+                                         1 if relu else 0, N.ptr(_bn_workspace(M, C, z.device)), N.ptr(dz), N.ptr(dres),
+                                         N.ptr(dgamma), N.ptr(dbeta), N.stream()), "lss_bn_train_bwd")
+    return dz, dres, dgamma, dbeta
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def conv_bn_act_train_fwd(x1n, x2n, weight, gamma, beta, resn, running_mean, running_var, momentum, eps, relu, up):
+    """One host call: conv3x3 (fused upsample/concat input) -> BN(train) -> (+res) -> ReLU.  Operands are
+    trusted (contiguous bf16 NHWC activations, fp32 parameters): the caller is modules._ConvBNActFn.
+    Returns z, y (bf16 NHWC), save_mean, save_invstd."""
+    B, H, W, Cx = x1n.shape
+    C2 = 0 if x2n is None else x2n.shape[3]
+    Cout = weight.shape[0]
+    dev = x1n.device
+    z = torch.empty(B, H * up, W * up, Cout, dtype=torch.bfloat16, device=dev)
+    y = torch.empty_like(z)
+    wp = torch.empty(9 * Cout * (Cx + C2), dtype=torch.bfloat16, device=dev)
+    stat = torch.empty(2, Cout, dtype=torch.float32, device=dev)
+    ws = _bn_workspace(B * H * up * W * up, Cout, dev)
+    with _timed("conv_bn_act_train_fwd"):
+        N.check(N.lib().lss_conv_bn_act_train_fwd(
+            x1n.data_ptr(), _p(x2n), weight.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(resn), _p(running_mean),
+            _p(running_var), wp.data_ptr(), z.data_ptr(), y.data_ptr(), stat.data_ptr(), stat.data_ptr() + 4 * Cout,
+            ws.data_ptr(), B, H, W, Cx, C2, up, Cout, momentum, eps, 1 if relu else 0, N.stream()),
+            "lss_conv_bn_act_train_fwd")
+    return z, y, stat
+
+
+def conv_bn_act_train_bwd(gyn, y, z, x1n, x2n, weight, gamma, stat, relu, up, want_res, want_x1, want_x2, want_w):
+    """Backward of conv_bn_act_train_fwd in one host call.  Returns (g1, g2, gw, dgamma, dbeta, dres)."""
+    B, H, W, Cx = x1n.shape
+    C2 = 0 if x2n is None else x2n.shape[3]
+    Cout, Ct = weight.shape[0], Cx + C2
+    Hh, Wh = H * up, W * up
+    dev = x1n.device
+    dz = torch.empty_like(z)
+    dres = torch.empty_like(z) if want_res else None
+    dgb = torch.empty(2, Cout, dtype=torch.float32, device=dev)
+    plain = up == 1 and C2 == 0
+    gcat = g1 = xcat = gw = wd = wws = None
+    nws = 0
+    if want_x1 or want_x2:
+        gcat = torch.empty(B, Hh, Wh, Ct, dtype=torch.bfloat16, device=dev)
+        wd = torch.empty(9 * Cout * Ct, dtype=torch.bfloat16, device=dev)
+        if want_x1 and not plain:
+            g1 = torch.empty(B, H, W, Cx, dtype=torch.bfloat16, device=dev)
+    if want_w:
+        gw = torch.empty(Cout, Ct, 3, 3, dtype=torch.float32, device=dev)
+        if not plain:
+            xcat = torch.empty(B, Hh, Wh, Ct, dtype=torch.bfloat16, device=dev)
+        nws = N.lib().lss_conv2d_wgrad_workspace_bytes(B, Hh, Wh, Ct, Cout)
+        key = (B, Hh, Wh, Ct, Cout, str(dev))
+        wws = _wgrad_ws.get(key)
+        if wws is None:
+            wws = _wgrad_ws[key] = torch.empty(nws, dtype=torch.uint8, device=dev)
+    ws = _bn_workspace(B * Hh * Wh, Cout, dev)
+    with _timed("conv_bn_act_train_bwd"):
+        N.check(N.lib().lss_conv_bn_act_train_bwd(
+            gyn.data_ptr(), y.data_ptr(), z.data_ptr(), x1n.data_ptr(), _p(x2n), weight.data_ptr(), gamma.data_ptr(),
+            stat.data_ptr(), stat.data_ptr() + 4 * Cout, ws.data_ptr(), _p(wws), nws, _p(wd), dz.data_ptr(), _p(dres),
+            dgb.data_ptr(), dgb.data_ptr() + 4 * Cout, _p(gcat), _p(g1), _p(xcat), _p(gw), B, H, W, Cx, C2, up, Cout,
+            1 if relu else 0, N.stream()), "lss_conv_bn_act_train_bwd")
+    if want_x1 and plain:
+        g1 = gcat
+    g2 = gcat[..., :C2] if (want_x2 and C2 > 0) else None
+    return g1, g2, gw, dgb[0], dgb[1], dres
+
+
 def pack_conv_weight_s2d(w_oihw, pad):
     """OIHW fp32 of a stride-2 k x k conv -> bf16 [tap'][Cout][4*Cin] for conv2d_s2_nhwc."""
     Cout, Cin, K, K2 = w_oihw.shape
