@@ -289,10 +289,10 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     return {"samples_per_s": args.train_steps * B * world / dt, "ms_per_step": dt / args.train_steps * 1e3,
             "steps": args.train_steps, "grad_bucket_MB": bucket.numel * 4 / 1e6,
             "amp_bf16": amp,
-            "note": "lift-splat fwd/bwd native HIP (fp32); under bf16 autocast BevEncode's 3x3/s1 convs (95 % of its "
-                    "FLOPs) run forward, dgrad and wgrad on the HIP kernels with the upsample/concat fused "
-                    "(LSS_TRAIN_NATIVE=0 disables); BatchNorm batch statistics, ReLU/add, the stride-2 and 1x1 "
-                    "convs, loss and Adam are torch/MIOpen ops"}
+            "note": "lift-splat fwd/bwd native HIP (fp32); under bf16 autocast every 3x3/s1 conv + BatchNorm(train) + "
+                    "residual + ReLU unit of BevEncode (95 % of its FLOPs) is one HIP autograd node: conv fwd / dgrad / "
+                    "wgrad, BN fwd / bwd, fused upsample+concat and its adjoint (LSS_TRAIN_NATIVE=0 = library path for "
+                    "A/B); the 7x7/2 stem, the stride-2 and 1x1 convs, loss and Adam are torch/MIOpen ops"}
 
 
 def host_cores():

@@ -42,6 +42,8 @@ __global__ void pack_weights_dgrad_kernel(const float* __restrict__ w, int Cout,
   }
 }
 
+constexpr int NCLR = 16;  // extra workgroup rows of the transposer that clear guards / K tail
+
 struct WgradGeom {
   int B, H, W, Wp;
   long long ktot;   // B*(H+2)*Wp rounded up to nsplit*32
@@ -77,8 +79,32 @@ __global__ __launch_bounds__(256) void to_channel_major_kernel(const unsigned sh
   extern __shared__ __attribute__((aligned(16))) unsigned short tile[];  // [64][Wp + 8]
   const int TS = Wp + 8;  // tile column j holds padded-image column x'' = j - 4
   const int tid = threadIdx.x;
-  const int yp = blockIdx.x % (H + 2), b = blockIdx.x / (H + 2);
   const int c0 = blockIdx.y * 64;
+  const int nrows = B * (H + 2);
+  if ((int)blockIdx.x >= nrows) {
+    // extra workgroups: clear the lead guard row (slice 0) and everything past the image grid
+    // (K tail + tail guard row; slices 1..NCLR-1) of this channel block's rows - no memset launches
+    const int slice = blockIdx.x - nrows;
+    const long long kimg = (long long)nrows * Wp;
+    long long lo, hi;
+    if (slice == 0) { lo = 0; hi = Wp; }
+    else {
+      const long long span8 = (ld - Wp - kimg) / 8, per = (span8 + NCLR - 2) / (NCLR - 1);
+      lo = Wp + kimg + 8 * min(span8, per * (slice - 1));
+      hi = Wp + kimg + 8 * min(span8, per * slice);
+    }
+    const long long n8 = (hi - lo) / 8;
+    for (long long e = tid; e < (long long)ncopy * 64 * n8; e += 256) {
+      const long long ch = e % n8;
+      const int c = (int)((e / n8) % 64);
+      const int copy = (int)(e / (n8 * 64));
+      if (c0 + c < C)
+        *reinterpret_cast<uint4*>(dst + (size_t)copy * copy_stride + (size_t)(c0 + c) * ld + lo + ch * 8) =
+            make_uint4(0, 0, 0, 0);
+    }
+    return;
+  }
+  const int yp = blockIdx.x % (H + 2), b = blockIdx.x / (H + 2);
   for (int e = tid; e < 64 * TS; e += 256) tile[e] = 0;
   __syncthreads();
   if (yp >= 1 && yp <= H) {
@@ -98,21 +124,6 @@ __global__ __launch_bounds__(256) void to_channel_major_kernel(const unsigned sh
     }
   }
   __syncthreads();
-  // the first / last workgroup of a channel block also clears the lead guard row and everything
-  // past the image grid (K tail + tail guard row) of its rows: no separate memset launches
-  if (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) {
-    const long long kimg = (long long)B * (H + 2) * Wp;
-    const long long lo = blockIdx.x == 0 ? 0 : Wp + kimg, hi = blockIdx.x == 0 ? Wp : ld;
-    const long long n8 = (hi - lo) / 8;
-    for (long long e = tid; e < (long long)ncopy * 64 * n8; e += 256) {
-      const long long ch = e % n8;
-      const int c = (int)((e / n8) % 64);
-      const int copy = (int)(e / (n8 * 64));
-      if (c0 + c < C)
-        *reinterpret_cast<uint4*>(dst + (size_t)copy * copy_stride + (size_t)(c0 + c) * ld + lo + ch * 8) =
-            make_uint4(0, 0, 0, 0);
-    }
-  }
   const long long flat0 = ((long long)b * (H + 2) + yp) * Wp + Wp;  // + Wp: the lead guard row
   const int chunks = Wp / 8;
   for (int e = tid; e < ncopy * 64 * chunks; e += 256) {
@@ -280,7 +291,7 @@ extern "C" int lss_conv2d_wgrad(const void* x, const void* dy, int B, int H, int
   const size_t dyt_bytes = align256((size_t)Cout * g.ld * 2);
   float* partial = reinterpret_cast<float*>(ws + xt_bytes + dyt_bytes);
   const size_t lds = (size_t)64 * (g.Wp + 8) * 2;
-  const dim3 gx(B * (H + 2), lss_cdiv(Cin, 64)), gy(B * (H + 2), lss_cdiv(Cout, 64));
+  const dim3 gx(B * (H + 2) + NCLR, lss_cdiv(Cin, 64)), gy(B * (H + 2) + NCLR, lss_cdiv(Cout, 64));
   hipLaunchKernelGGL(to_channel_major_kernel, gx, dim3(256), lds, st, static_cast<const unsigned short*>(x), B, H,
                      W, Cin, g.Wp, g.ld, (long long)Cin * g.ld, 3, xt);
   hipLaunchKernelGGL(to_channel_major_kernel, gy, dim3(256), lds, st, static_cast<const unsigned short*>(dy), B,
