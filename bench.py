@@ -97,9 +97,11 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    # the box exposes 256 logical CPUs but grants ~16: keep torch's intra-op pool (used by the
-    # per-step host calibration math) inside the grant
-    torch.set_num_threads(host_cores())
+    # The per-step host work of the GPU legs is a handful of 3x3 inverses and one pinned copy: it
+    # gains nothing from an intra-op pool, and with one rank per GPU on a shared node 8 x 16
+    # spinning OpenMP threads would contend for the same cores.  The cpu_baseline leg sets its own
+    # (full) thread count.
+    torch.set_num_threads(min(2, host_cores()))
     # rehearsal hook for a 1-GPU box: LSS_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo
     rehearse = os.environ.get("LSS_BENCH_REHEARSE") == "1"
     if rehearse:

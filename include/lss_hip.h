@@ -146,11 +146,12 @@ int lss_depthnet_softmax_fwd(const float* x, const float* w, const float* bias,
  *   softmax 1: depth = softmax over D; 0: depth = raw logits
  *   depth   (BN, D, HW) fp32 out;  feat (BN*HW, C) fp32 out (channels-last rows)
  *   Cd % 64 == 0, Cf % 64 == 0; D <= 64; C in {0, 49..64, 113..128}
- * Math: f32 MFMA (exact fp32 FMA chains), bf16 inputs widened exactly.
+ *   math    LSS_DT_F32: f32 MFMA (exact fp32 FMA chains, bf16 inputs widened exactly);
+ *           LSS_DT_BF16: operands rounded to bf16, fp32 accumulation (Cd, Cf % 128 == 0)
  */
 int lss_camencode_v2_fwd(const void* x_depth, int dt, const float* w_depth, const float* b_depth,
                          int Cd, const float* x_feat, const float* w_feat, const float* b_feat,
-                         int Cf, int BN, int HW, int D, int C, int softmax, float* depth,
+                         int Cf, int BN, int HW, int D, int C, int softmax, int math, float* depth,
                          float* feat, void* stream);
 
 /* MultiScaleDepthNet tail.

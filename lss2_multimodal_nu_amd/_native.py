@@ -27,7 +27,7 @@ SIGNATURES = {
     "lss_geom_to_voxels": (_i, [_vp, _vp, _vp] + [_i] * 5 + [_vp, _vp, _vp]),
     "lss_bucket_points": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lss_depthnet_softmax_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
-    "lss_camencode_v2_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp] + [_i] * 6 + [_vp, _vp, _vp]),
+    "lss_camencode_v2_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp] + [_i] * 7 + [_vp, _vp, _vp]),
     "lss_depth_fuse_softmax_fwd": (_i, [_vp] * 5 + [_i] * 6 + [_vp, _vp]),
     "lss_add_pos_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lss_deform_attn_fwd": (_i, [_vp, _i] + [_vp] * 4 + [_i] * 7 + [_vp, _vp]),

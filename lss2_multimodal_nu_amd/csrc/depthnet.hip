@@ -256,6 +256,78 @@ __global__ __launch_bounds__(256) void camencode_v2_kernel(
                         depth, feat);
 }
 
+// bf16-MFMA variant of the two-source kernel (conv path in bf16): operands rounded to bf16 in
+// registers (the hidden map usually IS bf16), fp32 accumulation on v_mfma_f32_16x16x32_bf16 -
+// 8x fewer MFMA issues than the f32 form, which at these tiny GEMMs is what the time is.
+template <typename T>
+__device__ __forceinline__ bf16x8 load_k8_bf16(const T* p);
+template <>
+__device__ __forceinline__ bf16x8 load_k8_bf16<unsigned short>(const unsigned short* p) {
+  return *reinterpret_cast<const bf16x8*>(p);
+}
+template <>
+__device__ __forceinline__ bf16x8 load_k8_bf16<float>(const float* p) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    r[e] = (short)lss_f2bf(a[e]);
+    r[4 + e] = (short)lss_f2bf(b[e]);
+  }
+  return r;
+}
+__device__ __forceinline__ bf16x8 w_k8_bf16(const float* p) { return load_k8_bf16<float>(p); }
+
+template <int NTD, int NTC, typename T>
+__global__ __launch_bounds__(256) void camencode_v2_bf16_kernel(
+    const T* __restrict__ xd, const float* __restrict__ wd, const float* __restrict__ bd, int Cd,
+    const float* __restrict__ xf, const float* __restrict__ wf, const float* __restrict__ bf, int Cf,
+    int HW, int D, int C, int softmax, float* __restrict__ depth, float* __restrict__ feat) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, j = lane >> 4;
+  const int bn = blockIdx.y;
+  const int pix0 = blockIdx.x * PIX;
+  const int pix = min(pix0 + col, HW - 1);
+  constexpr int NT = NTD + NTC;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bf16x8 zero8 = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  {  // depth logits from the NHWC hidden map: A[n][k = 8j + e], B[k = 8j + e][pix]
+    const int kq = Cd >> 2;
+    const T* xb = xd + ((size_t)bn * HW + pix) * Cd + (size_t)wave * kq + 8 * j;
+    const float* wb = wd + (size_t)wave * kq + 8 * j;
+    for (int kb = 0; kb < kq; kb += 32) {
+      const bf16x8 bx = load_k8_bf16<T>(xb + kb);
+#pragma unroll
+      for (int t = 0; t < NTD; ++t) {
+        const int n = 16 * t + col;
+        const bf16x8 wa = n < D ? w_k8_bf16(wb + (size_t)n * Cd + kb) : zero8;
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, bx, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if (NTC > 0) {  // context features from the NCHW trunk map
+    const int kq = Cf >> 2;
+    const float* xb = xf + ((size_t)bn * Cf + (size_t)wave * kq) * HW + pix;
+    const float* wb = wf + (size_t)wave * kq + 8 * j;
+    for (int kb = 0; kb < kq; kb += 32) {
+      bf16x8 bx;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bx[e] = (short)lss_f2bf(xb[(size_t)(kb + 8 * j + e) * HW]);
+#pragma unroll
+      for (int t = 0; t < NTC; ++t) {
+        const int n = 16 * t + col;
+        const bf16x8 wa = n < C ? w_k8_bf16(wb + (size_t)n * Cf + kb) : zero8;
+        acc[NTD + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, bx, acc[NTD + t], 0, 0, 0);
+      }
+    }
+  }
+  depthnet_epilogue<NT>(acc, lds, bd, bf, 16 * NTD, softmax != 0, bn, pix0, HW, D, NTC > 0 ? C : 0,
+                        depth, feat);
+}
+
 // MultiScaleDepthNet tail (ref: src/model_vovnet_transformer.py:61-70): bilinear
 // (align_corners=False) upsample of the coarse logits, concat, 1x1 fusion conv,
 // eval-mode BatchNorm (folded into scale/shift), ReLU, softmax over D.
@@ -348,22 +420,28 @@ extern "C" int lss_depthnet_softmax_fwd(const float* x, const float* w, const fl
 template <int NTD, int NTC, typename T>
 static int launch_camencode_v2(const void* xd, const float* wd, const float* bd, int Cd,
                                const float* xf, const float* wf, const float* bf, int Cf, int BN,
-                               int HW, int D, int C, int softmax, float* depth, float* feat,
+                               int HW, int D, int C, int softmax, float* depth, float* feat, int math,
                                hipStream_t st) {
   const size_t lds_bytes = (size_t)5 * (NTD + NTC) * 16 * LDS_LD * sizeof(float);
   dim3 grid(lss_cdiv(HW, PIX), BN);
-  hipLaunchKernelGGL((camencode_v2_kernel<NTD, NTC, T>), grid, dim3(256), lds_bytes, st,
-                     static_cast<const T*>(xd), wd, bd, Cd, xf, wf, bf, Cf, HW, D, C, softmax, depth,
-                     feat);
+  if (math == LSS_DT_BF16)
+    hipLaunchKernelGGL((camencode_v2_bf16_kernel<NTD, NTC, T>), grid, dim3(256), lds_bytes, st,
+                       static_cast<const T*>(xd), wd, bd, Cd, xf, wf, bf, Cf, HW, D, C, softmax, depth, feat);
+  else
+    hipLaunchKernelGGL((camencode_v2_kernel<NTD, NTC, T>), grid, dim3(256), lds_bytes, st,
+                       static_cast<const T*>(xd), wd, bd, Cd, xf, wf, bf, Cf, HW, D, C, softmax, depth, feat);
   return lss_launch_status();
 }
 
 extern "C" int lss_camencode_v2_fwd(const void* x_depth, int dt, const float* w_depth,
                                     const float* b_depth, int Cd, const float* x_feat,
                                     const float* w_feat, const float* b_feat, int Cf, int BN, int HW,
-                                    int D, int C, int softmax, float* depth, float* feat,
+                                    int D, int C, int softmax, int math, float* depth, float* feat,
                                     void* stream) {
   LSS_CHECK_PTR(x_depth); LSS_CHECK_PTR(w_depth); LSS_CHECK_PTR(b_depth); LSS_CHECK_PTR(depth);
+  if (math != LSS_DT_F32 && math != LSS_DT_BF16) return LSS_E_LAYOUT;
+  // each wave owns a K quarter in 16- (f32 MFMA) or 32-deep (bf16 MFMA) blocks
+  if (math == LSS_DT_BF16 && (Cd % 128 != 0 || (C > 0 && Cf % 128 != 0))) return LSS_E_SHAPE;
   LSS_CHECK_POS(BN); LSS_CHECK_POS(HW); LSS_CHECK_POS(D); LSS_CHECK_POS(Cd);
   if (dt != LSS_DT_F32 && dt != LSS_DT_BF16) return LSS_E_LAYOUT;
   if (C < 0 || (C > 0 && (x_feat == nullptr || w_feat == nullptr || b_feat == nullptr || feat == nullptr)))
@@ -378,10 +456,10 @@ extern "C" int lss_camencode_v2_fwd(const void* x_depth, int dt, const float* w_
   if (ntd == a && ntc == b)                                                                       \
     return dt == LSS_DT_F32                                                                       \
                ? launch_camencode_v2<a, b, float>(x_depth, w_depth, b_depth, Cd, x_feat, w_feat,  \
-                                                  b_feat, Cf, BN, HW, D, C, softmax, depth, feat, st) \
+                                                  b_feat, Cf, BN, HW, D, C, softmax, depth, feat, math, st) \
                : launch_camencode_v2<a, b, unsigned short>(x_depth, w_depth, b_depth, Cd, x_feat, \
                                                            w_feat, b_feat, Cf, BN, HW, D, C,      \
-                                                           softmax, depth, feat, st);
+                                                           softmax, depth, feat, math, st);
   LSS_V2_CASE(3, 0) LSS_V2_CASE(3, 4) LSS_V2_CASE(3, 8)
   LSS_V2_CASE(4, 0) LSS_V2_CASE(4, 4) LSS_V2_CASE(4, 8)
   LSS_V2_CASE(1, 0) LSS_V2_CASE(1, 1)

@@ -204,11 +204,12 @@ def depthnet_softmax(x, weight, bias, D, C, math=DT_F32):
     return depth, feat
 
 
-def camencode_v2(hidden, w_depth, b_depth, D, c3=None, w_feat=None, b_feat=None, softmax=True):
+def camencode_v2(hidden, w_depth, b_depth, D, c3=None, w_feat=None, b_feat=None, softmax=True, math=None):
     """K2v.  hidden (BN,fH,fW,Cd) NHWC fp32|bf16; w_depth (D,Cd[,1,1]); optional c3
     (BN,Cf,fH,fW) fp32 NCHW with w_feat (C,Cf[,1,1]) / b_feat.  Returns depth
     (BN,D,fH,fW) (probabilities, or raw logits with softmax=False) and feat
-    (BN,fH,fW,C) or None."""
+    (BN,fH,fW,C) or None.  math: DT_F32 (exact fp32 FMA chains) or DT_BF16 (bf16 MFMA, fp32
+    accumulate); default = the hidden map's own precision when the shapes allow."""
     BN, fH, fW, Cd = hidden.shape
     if not hidden.is_contiguous() or hidden.dtype not in (torch.float32, torch.bfloat16):
         raise ValueError("hidden must be contiguous NHWC fp32/bf16")
@@ -231,9 +232,11 @@ def camencode_v2(hidden, w_depth, b_depth, D, c3=None, w_feat=None, b_feat=None,
         args = (N.ptr(c3), N.ptr(wf), N.ptr(b_feat), Cf)
     else:
         C, feat, args = 0, None, (None, None, None, 0)
+    if math is None:
+        math = DT_BF16 if (dt == DT_BF16 and Cd % 128 == 0 and (C == 0 or args[3] % 128 == 0)) else DT_F32
     with _timed("camencode_v2"):
         N.check(N.lib().lss_camencode_v2_fwd(N.ptr(hidden), dt, N.ptr(wd), N.ptr(b_depth), Cd, *args, BN,
-                                             fH * fW, D, C, 1 if softmax else 0, N.ptr(depth),
+                                             fH * fW, D, C, 1 if softmax else 0, math, N.ptr(depth),
                                              N.ptr(feat) if feat is not None else None, N.stream()),
                 "lss_camencode_v2_fwd")
     return depth, feat
