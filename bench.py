@@ -248,8 +248,10 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     tgt = torch.randint(0, 4, (B, 200, 200), device=dev)
     weight = torch.tensor([1.0, 10.0, 5.0, 10.0], device=dev)         # ref: src/tools.py:234
 
-    def loss_fn(y):
-        return torch.nn.functional.cross_entropy(y.float(), tgt, weight=weight)
+    from lss2_multimodal_nu_amd.tools import weighted_cross_entropy
+
+    def loss_fn(y):  # SimpleLoss, ref: src/tools.py:221-231 (fused HIP forward/backward)
+        return weighted_cross_entropy(y.float(), tgt, weight)
 
     amp = args.precision == "bf16"  # bf16 autocast for the (library) BevEncode convs, fp32 master weights
 

@@ -336,6 +336,21 @@ int lss_conv_bn_act_train_bwd(const void* dy, const void* y, const void* z, cons
                               int B, int H, int W, int Cx, int C2, int up, int Cout, int relu,
                               void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Weighted cross-entropy over NCHW logits.
+ * replaces: nn.CrossEntropyLoss(weight)(ypred, ytgt) of SimpleLoss / MultiLoss, src/tools.py:221-238
+ *           (log_softmax + nll_loss2d, forward and backward).
+ *   logits (B, C, H*W) fp32, C <= 16; target (B, H*W) int64 (entries outside [0, C) are ignored);
+ *   weight (C) fp32;  loss = sum w[t] * nll / sum w[t].
+ *   workspace: 512 floats.  sums (2) fp32 out: {sum w*nll, sum w} - kept for the backward.
+ *   backward: grad_logits (B, C, H*W) fp32 = grad_loss[0] * w[t] * (softmax - onehot) / sums[1].
+ */
+int lss_weighted_ce_fwd(const float* logits, const long long* target, const float* weight, int B, int C,
+                        long long HW, float* workspace, float* sums, float* loss, void* stream);
+int lss_weighted_ce_bwd(const float* logits, const long long* target, const float* weight, int B, int C,
+                        long long HW, const float* sums, const float* grad_loss, float* grad_logits,
+                        void* stream);
+
 /* Stride-2 convs (3x3 pad 1, 7x7 pad 3, and 1x1 pad 0 with the plain weight pack;
  * bf16) on the LDS-tiled MFMA kernel: the
  * conv is evaluated as a stride-1 conv over the 4 parity phases of the input

@@ -28,6 +28,7 @@ SOURCES = {
     "linear_mfma.hip": [],
     "conv_grad.hip": [],
     "bn_train.hip": [],
+    "loss.hip": [],
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-variable",
           "-Wno-unused-but-set-variable"]

@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from . import ops
+from .data import CalibrationPack, calib_matrices
 from .heads import (BevPost, Embedder_f1, Embedder_f2, Embedder_lr1, Embedder_lr2, Predictor,
                     SceneUnder)
 from .modules import BevEncode, CamEncode, _PRECISIONS, _needs_autograd, default_precision
@@ -155,12 +156,20 @@ class _LiftSplatMixin:
         CPU calibration tensors (what a DataLoader hands over) cost no sync.
         Both inverses go through ONE flattened (2*B*N, 3, 3) call: bitwise the same
         matrices as the reference's two 4-D calls (tests/test_modules_cpu.py), ~8x less
-        host time."""
-        r, i, p = (t.detach().float().cpu().reshape(-1, 3, 3) for t in (rots, intrins, post_rots))
-        n = p.shape[0]
-        inv = torch.inverse(torch.cat([p, i]))
-        shape = tuple(rots.shape)
-        return inv[:n].view(shape), torch.bmm(r, inv[n:]).view(shape)
+        host time.  `data.prepare_calibration` does the same in the loader instead."""
+        return calib_matrices(rots, intrins, post_rots)
+
+    def _device_calib(self, dev, rots, trans, intrins, post_rots, post_trans):
+        """(inv_post_rots, combine, post_trans, trans) on the device.  A `CalibrationPack` passed as
+        `rots` (built by the DataLoader, data.prepare_calibration) skips the host linear algebra: its
+        buffer goes up in one copy; otherwise the matrices are computed here and staged."""
+        if isinstance(rots, CalibrationPack):
+            d = rots.buffer.to(dev, non_blocking=True)
+            self._packs = (getattr(self, "_packs", ()) + (rots,))[-8:]  # keep pinned sources alive until copied
+            return rots.views(d)
+        inv_pr, comb = self._calib_matrices(rots, intrins, post_rots)
+        inv_pr, comb, ptr, trn = self._upload(dev, inv_pr, comb, post_trans, trans)
+        return inv_pr, comb, ptr, trn
 
     def _upload(self, device, *ts):
         """Host tensors -> one pinned staging block -> one async H2D copy -> device views.
@@ -193,11 +202,10 @@ class _LiftSplatMixin:
     def _index_points(self, rots, trans, intrins, post_rots, post_trans, want_geom=False):
         """K3 (+K4): fills the workspace; returns (workspace, geom or None)."""
         dev = self.frustum.device
-        B, Ncam = trans.shape[:2]
+        inv_pr, comb, ptr, trn = self._device_calib(dev, rots, trans, intrins, post_rots, post_trans)
+        B, Ncam = trn.shape[:2]
         D, fH, fW, _ = self.frustum.shape
         nx = self._nx_ints()
-        inv_pr, comb = self._calib_matrices(rots, intrins, post_rots)
-        inv_pr, comb, ptr, trn = self._upload(dev, inv_pr, comb, post_trans, trans)
         ws = self._workspace(B * Ncam * D * fH * fW, B * nx[0] * nx[1] * nx[2], dev)
         geom = ops.points_to_voxels(self.frustum.detach(), inv_pr, ptr, comb, trn, self.dx.detach(),
                                     self.bx.detach(), nx, ws, want_geom=want_geom)
@@ -234,9 +242,9 @@ class _LiftSplatMixin:
         """Fused path: trunk features + calibration -> BEV (logical (B, C*nz, nx, ny))."""
         BN, _, fH, fW = x.shape
         B = self.bsize
-        if BN % B != 0 or tuple(trans.shape[:2]) != (B, BN // B):
-            raise RuntimeError("features for %d images do not match bsize=%d x %s cameras"
-                               % (BN, B, tuple(trans.shape[:2])))
+        cshape = rots.shape if isinstance(rots, CalibrationPack) else tuple(trans.shape[:2])
+        if BN % B != 0 or tuple(cshape) != (B, BN // B):
+            raise RuntimeError("features for %d images do not match bsize=%d x %s cameras" % (BN, B, tuple(cshape)))
         if (self.D, fH, fW) != tuple(self.frustum.shape[:3]):
             raise RuntimeError("feature map %dx%d does not match the frustum %s"
                                % (fH, fW, tuple(self.frustum.shape[:3])))
@@ -249,8 +257,7 @@ class _LiftSplatMixin:
         # inference: K3 -> K2 -> K4 -> K5 through one native call
         dev = self.frustum.device
         nx = self._nx_ints()
-        inv_pr, comb = self._calib_matrices(rots, intrins, post_rots)
-        inv_pr, comb, ptr, trn = self._upload(dev, inv_pr, comb, post_trans, trans)
+        inv_pr, comb, ptr, trn = self._device_calib(dev, rots, trans, intrins, post_rots, post_trans)
         ws = self._workspace(B * dims[1] * self.D * fH * fW, B * nx[0] * nx[1] * nx[2], dev)
         with ops.region("lift_splat_level"):
             bev, _, _ = ops.lift_splat_forward(self.frustum.detach(), inv_pr, ptr, comb, trn, self.dx.detach(),

@@ -291,10 +291,11 @@ class VoVNetBEVTransformer(_LiftSplatMixin, nn.Module):
     def get_voxels(self, c3, c4, rots, trans, intrins, post_rots, post_trans, layout=ops.BEV_NCHW_F32):
         """Trunk maps + calibration -> BEV grid (B, C*nz, nx, ny) [logical shape]."""
         BN, _, fH, fW = c3.shape
-        B = rots.shape[0]
+        B = rots.shape[0]  # (a data.CalibrationPack has .shape = (B, N) too)
         Ncam = BN // B
-        if BN % B != 0 or tuple(trans.shape[:2]) != (B, Ncam):
-            raise RuntimeError("features for %d images do not match %s calibrations" % (BN, tuple(trans.shape[:2])))
+        cshape = tuple(rots.shape[:2]) if trans is None else tuple(trans.shape[:2])
+        if BN % B != 0 or cshape != (B, Ncam):
+            raise RuntimeError("features for %d images do not match %s calibrations" % (BN, cshape))
         if (self.D, fH, fW) != tuple(self.frustum.shape[:3]):
             raise RuntimeError("feature map %dx%d / D=%d does not match the frustum %s"
                                % (fH, fW, self.D, tuple(self.frustum.shape[:3])))

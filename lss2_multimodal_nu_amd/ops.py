@@ -656,6 +656,34 @@ def conv_bn_act_train_bwd(gyn, y, z, x1n, x2n, weight, gamma, stat, relu, up, wa
     return g1, g2, gw, dgb[0], dgb[1], dres
 
 
+def weighted_ce_fwd(logits, target, weight):
+    """loss (1-element fp32 tensor) and the saved sums for weighted_ce_bwd.  logits (B,C,...) fp32
+    contiguous, target (B,...) int64 contiguous, weight (C) fp32."""
+    B, C = logits.shape[:2]
+    _f32c(logits, "logits")
+    _f32c(weight, "weight", (C,))
+    if target.dtype != torch.int64 or not target.is_contiguous() or target.numel() * C != logits.numel():
+        raise ValueError("target must be contiguous int64 of shape (B, ...) matching the logits")
+    HW = logits.numel() // (B * C)
+    ws = torch.empty(512 + 3, dtype=torch.float32, device=logits.device)
+    with _timed("weighted_ce_fwd"):
+        N.check(N.lib().lss_weighted_ce_fwd(N.ptr(logits), N.ptr(target), N.ptr(weight), B, C, HW, ws.data_ptr(),
+                                            ws.data_ptr() + 4 * 512, ws.data_ptr() + 4 * 514, N.stream()),
+                "lss_weighted_ce_fwd")
+    return ws[514:515].view(()), ws[512:514]
+
+
+def weighted_ce_bwd(logits, target, weight, sums, grad_loss):
+    B, C = logits.shape[:2]
+    HW = logits.numel() // (B * C)
+    g = torch.empty_like(logits)
+    gl = grad_loss.reshape(1).float().contiguous()
+    with _timed("weighted_ce_bwd"):
+        N.check(N.lib().lss_weighted_ce_bwd(N.ptr(logits), N.ptr(target), N.ptr(weight), B, C, HW, N.ptr(sums),
+                                            N.ptr(gl), N.ptr(g), N.stream()), "lss_weighted_ce_bwd")
+    return g
+
+
 def pack_conv_weight_s2d(w_oihw, pad):
     """OIHW fp32 of a stride-2 k x k conv -> bf16 [tap'][Cout][4*Cin] for conv2d_s2_nhwc."""
     Cout, Cin, K, K2 = w_oihw.shape

@@ -66,3 +66,54 @@ class QuickCumsum(torch.autograd.Function):
         last, = ctx.saved_tensors
         run_of_row = torch.cumsum(last, 0) - last.to(torch.int64)
         return gradx[run_of_row], None, None
+
+
+class _WeightedCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, weight):
+        x = logits.float().contiguous()
+        t = target.contiguous()
+        w = weight.float().contiguous()
+        loss, sums = ops.weighted_ce_fwd(x, t, w)
+        ctx.save_for_backward(x, t, w, sums)
+        ctx.in_dtype = logits.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t, w, sums = ctx.saved_tensors
+        gx = ops.weighted_ce_bwd(x, t, w, sums, g)
+        return gx.to(ctx.in_dtype), None, None
+
+
+def weighted_cross_entropy(ypred, ytgt, weight):
+    """nn.CrossEntropyLoss(weight=weight)(ypred, ytgt) for (B,C,H,W) logits / (B,H,W) int64 targets:
+    one HIP pass forward, one backward on the GPU (csrc/loss.hip); torch's own op elsewhere."""
+    if ypred.is_cuda and ypred.dim() >= 3 and ypred.shape[1] <= 16 and ytgt.dtype == torch.int64:
+        return _WeightedCEFn.apply(ypred, ytgt, weight)
+    return torch.nn.functional.cross_entropy(ypred, ytgt, weight=weight)
+
+
+class SimpleLoss(torch.nn.Module):
+    """ref: src/tools.py:221-231 - weighted 4-class BEV cross-entropy, class weights [1, 10, 5, 10]."""
+
+    def __init__(self, class_weights=(1.0, 10.0, 5.0, 10.0)):
+        super().__init__()
+        self.register_buffer("weight", torch.tensor(class_weights, dtype=torch.float32), persistent=False)
+
+    def forward(self, ypred, ytgt):
+        return weighted_cross_entropy(ypred, ytgt, self.weight.to(ypred.device))
+
+
+def MultiLoss(bev_pre, act_pre, desc_pre, bev_gt, act_gt, desc_gt, args=None):
+    """ref: src/tools.py:234-252 - BEV cross-entropy [1,10,5,10] + weighted BCE-with-logits on the
+    action [1,5,5,5] and description [1,5,5,5,1,1,1,1] heads (those two are 4- and 8-element rows:
+    library ops)."""
+    dev = bev_pre.device
+    F = torch.nn.functional
+    loss_bev = weighted_cross_entropy(bev_pre, bev_gt, torch.tensor([1.0, 10.0, 5.0, 10.0], device=dev))
+    w1 = torch.tensor([1.0, 5.0, 5.0, 5.0], device=dev)
+    w2 = torch.tensor([1.0, 5.0, 5.0, 5.0, 1.0, 1.0, 1.0, 1.0], device=dev)
+    loss_act = F.binary_cross_entropy_with_logits(act_pre.to(dev), act_gt, weight=w1)
+    loss_desc = F.binary_cross_entropy_with_logits(desc_pre.to(dev), desc_gt, weight=w2)
+    return loss_bev + loss_act + loss_desc

@@ -274,3 +274,43 @@ def test_graft_entry_smoke():
     """The driver's smoke() entry point must keep working (it runs the whole hot path)."""
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_forward_with_loader_side_calibration_pack_is_bitwise_identical(model, golden):
+    """the DataLoader-built CalibrationPack skips the per-step host inverses and must not
+    change a single bit of the result (exact-index contract)."""
+    g = golden("g3_train_b1_s0")
+    calib = [torch.from_numpy(g[k]) for k in ("rots", "trans", "intrins", "post_rots", "post_trans")]
+    pack = L.prepare_calibration(*calib)
+    assert pack.buffer.is_pinned() and pack.shape == (1, 6)
+    torch.manual_seed(11)
+    x = torch.randn(6, 512, 8, 22).cuda()
+    with torch.no_grad():
+        a = model.get_voxels(x, *calib)
+        b = model.get_voxels(x, pack, None, None, None, None)
+        ya = model(x, *calib)
+        yb = model(x, pack, None, None, None, None)
+    assert torch.equal(a, b) and torch.equal(ya, yb)
+
+
+@pytest.mark.parametrize("C", [4, 7])
+def test_weighted_cross_entropy_fused_vs_torch(C):
+    """SimpleLoss / MultiLoss' BEV term, forward and backward, incl. ignored pixels."""
+    from lss2_multimodal_nu_amd.tools import SimpleLoss, weighted_cross_entropy
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(3, C, 50, 37, generator=g) * 3).cuda().requires_grad_(True)
+    t = torch.randint(0, C, (3, 50, 37), generator=g)
+    t[0, :5] = -100  # ignore_index rows
+    t = t.cuda()
+    w = (torch.rand(C, generator=g) * 9 + 1).cuda()
+    loss = weighted_cross_entropy(x, t, w)
+    (loss * 1.7).backward()
+    xr = x.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, t, weight=w)
+    (ref * 1.7).backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert float((x.grad - xr.grad).abs().max()) <= 1e-5 * float(xr.grad.abs().max())
+    if C == 4:
+        sl = SimpleLoss().cuda()
+        ref4 = torch.nn.functional.cross_entropy(xr.detach(), t, weight=torch.tensor([1.0, 10.0, 5.0, 10.0]).cuda())
+        assert abs(float(sl(x.detach(), t)) - float(ref4)) <= 1e-5 * abs(float(ref4))

@@ -48,7 +48,7 @@ def _placeholder(name):
 _ABSENT = [
     "torchvision", "torchvision.transforms", "torchvision.models",
     "torchvision.models.resnet", "efficientnet_pytorch", "pyquaternion", "cv2",
-    "nuscenes", "nuscenes.utils", "nuscenes.utils.data_classes",
+    "nuscenes", "nuscenes.nuscenes", "nuscenes.utils", "nuscenes.utils.splits", "nuscenes.utils.data_classes",
     "nuscenes.utils.geometry_utils", "nuscenes.map_expansion",
     "nuscenes.map_expansion.map_api",
 ]

@@ -260,5 +260,34 @@ def main():
              scale=np.array(sf), training=np.array(train), **d)
 
 
+def gen_host_input_path(rtools):
+    """G12: the reference's own img_transform (src/tools.py:117-142) and sample_augmentation
+    (src/data.py:90-112) on seeded draws - the calibration half of the loader."""
+    import types
+
+    from PIL import Image
+    import src.data as rdata
+    conf = {"resize_lim": (0.193, 0.225), "final_dim": (128, 352), "rot_lim": (-5.4, 5.4), "H": 900, "W": 1600,
+            "rand_flip": True, "bot_pct_lim": (0.0, 0.22)}
+    out = {}
+    for mode, is_train in (("train", True), ("val", False)):
+        np.random.seed(123)
+        fake = types.SimpleNamespace(data_aug_conf=conf, is_train=is_train)
+        rows, prs, pts = [], [], []
+        for _ in range(8):
+            resize, resize_dims, crop, flip, rotate = rdata.NuscData.sample_augmentation(fake)
+            img = Image.new("RGB", (1600, 900))
+            _, pr, pt = rtools.img_transform(img, torch.eye(2), torch.zeros(2), resize=resize, resize_dims=resize_dims,
+                                             crop=crop, flip=flip, rotate=rotate)
+            rows.append([resize, resize_dims[0], resize_dims[1], *crop, float(flip), rotate])
+            prs.append(pr.numpy())
+            pts.append(pt.numpy())
+        out[mode + "_params"] = np.array(rows, dtype=np.float64)
+        out[mode + "_post_rot"] = np.stack(prs)
+        out[mode + "_post_tran"] = np.stack(pts)
+    save("g12_host_input_path", **out)
+
+
 if __name__ == "__main__":
     main()
+    gen_host_input_path(load_reference()[0])
