@@ -512,6 +512,16 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
   };
   const int nchunks = a.Cin / 64;
 
+  // per-lane epilogue constants, fetched now so their latency is long gone by the epilogue
+  float esc[2], esh[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int co = n0 + wc * 64 + ct * 32 + r;
+    const bool cok = co < a.Cout;
+    esc[ct] = (cok && a.scale) ? a.scale[co] : 1.f;
+    esh[ct] = (cok && a.shift) ? a.shift[co] : 0.f;
+  }
+
   // prologue: W(0), W(1) on their way; patch of chunk 0
   issue_w(0, 0);
   if (nsteps > 1) issue_w(1, 1);
@@ -594,13 +604,30 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
   // residual (one 16-B load), ReLU, rounds to bf16 once, and stores 16 B.
   float* otile = reinterpret_cast<float*>(smem);
   // (the loop's final lds_barrier already guarantees every wave is done reading LDS)
+  // residual rows of this thread's output pieces: issued BEFORE the accumulators are staged, so
+  // the loads fly during the LDS write / barrier / read-back instead of stalling the store loop
+  constexpr int EPI = (TH * 16 * (BN / 8) + 255) / 256;
+  uint4 rres[EPI];
+  {
+    const unsigned short* resp = reinterpret_cast<const unsigned short*>(a.residual);
+#pragma unroll
+    for (int it = 0; it < EPI; ++it) {
+      const int e = tid + it * 256;
+      const int pl = e / (BN / 8), c8 = e % (BN / 8);
+      const int oy = oy0 + (pl >> 4), ox = ox0 + (pl & 15);
+      const int co = n0 + c8 * 8;
+      rres[it] = make_uint4(0, 0, 0, 0);
+      if (resp && !a.head_out && e < TH * 16 * (BN / 8) && oy < a.Ho && ox < a.Wo && co + 8 <= a.Cout &&
+          (a.Cout & 7) == 0)
+        rres[it] = *reinterpret_cast<const uint4*>(resp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + co);
+    }
+  }
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
     const int cl = wc * 64 + ct * 32 + r;  // channel within the tile
     const int co = n0 + cl;
     const bool cok = co < a.Cout;
-    const float sc = (cok && a.scale) ? a.scale[co] : 1.f;
-    const float sh = (cok && a.shift) ? a.shift[co] : 0.f;
+    const float sc = esc[ct], sh = esh[ct];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -660,7 +687,10 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
   unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
   const unsigned short* res = reinterpret_cast<const unsigned short*>(a.residual);
   const bool vec_ok = (a.Cout & 7) == 0;  // 16-B aligned channel groups
-  for (int e = tid; e < TH * 16 * (BN / 8); e += 256) {
+#pragma unroll
+  for (int it = 0; it < EPI; ++it) {
+    const int e = tid + it * 256;
+    if (e >= TH * 16 * (BN / 8)) continue;
     const int pl = e / (BN / 8), c8 = e % (BN / 8);
     const int oy = oy0 + (pl >> 4), ox = ox0 + (pl & 15);
     const int co = n0 + c8 * 8;
@@ -671,7 +701,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
     const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
     if (vec_ok && co + 8 <= a.Cout) {
       if (res) {
-        const uint4 rv = *reinterpret_cast<const uint4*>(res + o);
+        const uint4 rv = rres[it];
         const unsigned int ru[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
