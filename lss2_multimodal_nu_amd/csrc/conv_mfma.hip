@@ -312,22 +312,32 @@ __device__ __forceinline__ void wait_vmcnt() {
 // RT = 32-pixel MFMA row tiles per wave (2: 4 image rows x 64 channels per wave, the
 // throughput shape; 1: 2 image rows, half the work per workgroup - used when the RT = 2
 // grid would leave CUs idle, where the per-workgroup critical path is what counts).
-template <int RT, int BN, int MODE, int KH, int KW, int PAD>
-__global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX, int tilesY) {
+template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64>
+__global__ __launch_bounds__(256, KC == 32 ? 3 : 2) void conv_lds_kernel(ConvArgs a, int tilesX, int tilesY) {
+  // KC = input channels per (chunk, tap) step.  64: the default.  32: half-depth slabs and patch
+  // (39 KB of LDS, <= 168 VGPRs) so THREE workgroups share a CU - used for the big stride-1 layers,
+  // whose 728 / 1300 tiles then run in one / two full rounds instead of 1.4 / 2.5 on 512 slots.
+  static_assert(KC == 64 || KC == 32, "KC");
+  constexpr int PPP = KC / 8;   // 16-B pieces per patch position
+  constexpr int KS = KC / 16;   // MFMA k-steps per tap
+  constexpr int PSH = KC == 64 ? 3 : 2;  // log2(PPP)
   constexpr int TH = (4 / (BN / 64)) * RT * 2;  // image rows per workgroup
   constexpr bool FUSED = MODE == 1;
   constexpr int NT = KH * KW;
-  constexpr int TW = 16, IW = TW + KW - 1, IH = TH + KH - 1, POSB = 144;
-  constexpr int IROWB = (IW * POSB + 255) / 256 * 256;  // 2816
+  constexpr int TW = 16, IW = TW + KW - 1, IH = TH + KH - 1, POSB = KC * 2 + 16;
+  constexpr int IROWB = (IW * POSB + 255) / 256 * 256;  // 2816 (KC = 64), 1536 (KC = 32)
   constexpr int IN_BYTES = IH * IROWB;
-  constexpr int W_BYTES = BN * 128;
-  constexpr int WPT = BN / 32;    // LDS-DMA instructions per wave per step (1 KiB each)
+  constexpr int W_BYTES = BN * KC * 2;
+  constexpr int WPT = W_BYTES / 4096;  // LDS-DMA instructions per wave per step (1 KiB each)
   constexpr int WCOLS = BN / 64;  // waves along the channel axis
-  constexpr int IPT = (IH * IW * 8 + 255) / 256;  // 16-B patch pieces per thread per chunk
+  constexpr int IPT = (IH * IW * PPP + 255) / 256;  // 16-B patch pieces per thread per chunk
   constexpr int OLD = BN + 4;  // fp32 row stride of the epilogue's staged output tile
-  constexpr int OUT_BYTES = TH * 16 * OLD * 4;
+  // the epilogue stages the fp32 output tile in LDS: whole (KC = 64) or in two halves of TH/2 rows
+  constexpr int EPH = KC == 32 ? 2 : 1;
+  constexpr int OUT_BYTES = (TH / EPH) * 16 * OLD * 4;
   constexpr int SMEM_BYTES = (3 * W_BYTES + IN_BYTES) > OUT_BYTES ? (3 * W_BYTES + IN_BYTES) : OUT_BYTES;
-  static_assert(SMEM_BYTES <= 80 * 1024, "two workgroups must fit one CU's 160 KiB of LDS");
+  static_assert(SMEM_BYTES <= (KC == 32 ? 53 : 80) * 1024, "two (three) workgroups must fit one CU's 160 KiB of LDS");
+  static_assert(KC == 64 || (RT == 2 && BN == 128 && MODE != 2), "KC = 32 is built for the RT = 2, BN = 128 stride-1 tiles");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
   unsigned char* w_tile = smem;
   unsigned char* in_tile = smem + 3 * W_BYTES;
@@ -354,12 +364,14 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
 
   int aoff[RT], boff[2][4];
 #pragma unroll
-  for (int i = 0; i < RT; ++i) aoff[i] = (prow0 + 2 * i + (r >> 4)) * IROWB + (r & 15) * POSB + h * 64;
+  for (int i = 0; i < RT; ++i) aoff[i] = (prow0 + 2 * i + (r >> 4)) * IROWB + (r & 15) * POSB + h * KC;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = wc * 64 + i * 32 + r;
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) boff[i][s4] = row * 128 + (((4 * h + s4) ^ ((row >> 1) & 7)) << 4);
+    for (int s4 = 0; s4 < KS; ++s4)
+      boff[i][s4] = KC == 64 ? row * 128 + (((4 * h + s4) ^ ((row >> 1) & 7)) << 4)
+                             : row * 64 + (((2 * h + s4) ^ ((row >> 2) & 3)) << 4);
   }
   f32x16 acc[RT][2];
 #pragma unroll
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const unsigned short* wg = reinterpret_cast<const unsigned short*>(a.w);
-  const int nsteps = (a.Cin / 64) * NT;
+  const int nsteps = (a.Cin / KC) * NT;
   uint4 ireg[IPT];
   // weight slab of `step` -> ring slot: lane l of DMA block k lands at byte k*1024 + l*16,
   // i.e. row 8k + (l >> 3), 16-B slot l & 7, which must hold channel piece slot ^ swz(row)
@@ -379,10 +391,10 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       const int blk = i * 4 + wave;
-      const int row = blk * 8 + (lane >> 3);
-      const int part = (lane & 7) ^ ((row >> 1) & 7);
+      const int row = KC == 64 ? blk * 8 + (lane >> 3) : blk * 16 + (lane >> 2);
+      const int part = KC == 64 ? (lane & 7) ^ ((row >> 1) & 7) : (lane & 3) ^ ((row >> 2) & 3);
       const int co = min(n0 + row, a.Cout - 1);  // rows past Cout: any valid address (never stored)
-      glds16(wg + ((size_t)tap * a.Cout + co) * a.Cin + chunk * 64 + part * 8,
+      glds16(wg + ((size_t)tap * a.Cout + co) * a.Cin + chunk * KC + part * 8,
              w_tile + slot * W_BYTES + blk * 1024);
     }
   };
@@ -402,8 +414,8 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
     for (int i = 0; i < IPT; ++i) {
       const int q = tid + i * 256;
       g_off[i] = 0; g_w[i] = 0;
-      if (q < IH * IW * 8) {
-        const int pos = q >> 3, part = q & 7;
+      if (q < IH * IW * PPP) {
+        const int pos = q >> PSH, part = q & (PPP - 1);
         const int py = pos / IW, px = pos - py * IW;
         const int iy = oy0 - PAD + py, ix = ox0 - PAD + px;
         if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
@@ -421,14 +433,14 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
   auto gather_fused = [&](int chunk) {
     const unsigned short* xp = reinterpret_cast<const unsigned short*>(a.x);
     const unsigned short* x2p = reinterpret_cast<const unsigned short*>(a.x2);
-    const int c0 = chunk * 64;
+    const int c0 = chunk * KC;
     const bool skip = c0 < a.C2;  // chunk of the skip tensor x2: plain copy
     const int dxs = a.Cx, dys = a.W * a.Cx;
 #pragma unroll 2
     for (int i = 0; i < IPT; ++i) {
       const int q = tid + i * 256;
-      if (q >= IH * IW * 8) continue;
-      const int pos = q >> 3, part = q & 7;
+      if (q >= IH * IW * PPP) continue;
+      const int pos = q >> PSH, part = q & (PPP - 1);
       const int py = pos / IW, px = pos - py * IW;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (g_off[i] & 4) {
@@ -456,13 +468,13 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
   auto gather_in = [&](int chunk, bool to_lds) {
     if (FUSED) {
 #pragma unroll 1
-      for (int q = tid; q < IH * IW * 8; q += 256) {
-        const int pos = q >> 3, part = q & 7;
+      for (int q = tid; q < IH * IW * PPP; q += 256) {
+        const int pos = q >> PSH, part = q & (PPP - 1);
         const int py = pos / IW, px = pos - py * IW;
         const int iy = oy0 - PAD + py, ix = ox0 - PAD + px;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
-          v = load_in_piece<unsigned short, true>(a, b, iy, ix, chunk * 64 + part * 8);
+          v = load_in_piece<unsigned short, true>(a, b, iy, ix, chunk * KC + part * 8);
         *reinterpret_cast<uint4*>(in_tile + py * IROWB + px * POSB + part * 16) = v;
       }
     } else {
@@ -470,19 +482,19 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
       for (int i = 0; i < IPT; ++i) {
         const int q = tid + i * 256;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (q < IH * IW * 8) {
-          const int pos = q >> 3, part = q & 7;
+        if (q < IH * IW * PPP) {
+          const int pos = q >> PSH, part = q & (PPP - 1);
           const int py = pos / IW, px = pos - py * IW;
           int iy = oy0 - PAD + py, ix = ox0 - PAD + px, cc = chunk;
           if (MODE == 2) {  // (iy, ix) are phase-plane coordinates; chunk -> (phase, channel block)
-            const int nblk = a.Cx >> 6;
+            const int nblk = a.Cx / KC;
             const int ph = chunk / nblk;
             cc = chunk - ph * nblk;
             iy = 2 * iy + (ph >> 1);
             ix = 2 * ix + (ph & 1);
           }
           if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
-            v = load_in_piece<unsigned short, false>(a, b, iy, ix, cc * 64 + part * 8);
+            v = load_in_piece<unsigned short, false>(a, b, iy, ix, cc * KC + part * 8);
           if (to_lds) *reinterpret_cast<uint4*>(in_tile + py * IROWB + px * POSB + part * 16) = v;
         }
         if (!to_lds) ireg[i] = v;
@@ -493,8 +505,8 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
       const int q = tid + i * 256;
-      if (q < IH * IW * 8) {
-        const int pos = q >> 3, part = q & 7;
+      if (q < IH * IW * PPP) {
+        const int pos = q >> PSH, part = q & (PPP - 1);
         const int py = pos / IW, px = pos - py * IW;
         *reinterpret_cast<uint4*>(in_tile + py * IROWB + px * POSB + part * 16) = ireg[i];
       }
@@ -504,13 +516,13 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
   // one 1-KiB LDS-DMA block of the slab of `step` (block index i of this wave)
   auto issue_w1 = [&](int tap, int chunk, int slot, int i) {
     const int blk = i * 4 + wave;
-    const int row = blk * 8 + (lane >> 3);
-    const int part = (lane & 7) ^ ((row >> 1) & 7);
+    const int row = KC == 64 ? blk * 8 + (lane >> 3) : blk * 16 + (lane >> 2);
+    const int part = KC == 64 ? (lane & 7) ^ ((row >> 1) & 7) : (lane & 3) ^ ((row >> 2) & 3);
     const int co = min(n0 + row, a.Cout - 1);
-    glds16(wg + ((size_t)tap * a.Cout + co) * a.Cin + chunk * 64 + part * 8,
+    glds16(wg + ((size_t)tap * a.Cout + co) * a.Cin + chunk * KC + part * 8,
            w_tile + slot * W_BYTES + blk * 1024);
   };
-  const int nchunks = a.Cin / 64;
+  const int nchunks = a.Cin / KC;
 
   // per-lane epilogue constants, fetched now so their latency is long gone by the epilogue
   float esc[2], esh[2];
@@ -562,9 +574,9 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
       const bool prefetch = !FUSED && tap == PF_TAP && !last_chunk;
       const int slot2 = slot >= 1 ? slot - 1 : 2;  // (slot + 2) % 3
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
+      for (int s4 = 0; s4 < KS; ++s4) {
         const int cur = s4 & 1, nxt = cur ^ 1;
-        if (s4 < 3) {
+        if (s4 < KS - 1) {
           read_a(nxt, tap, s4 + 1);
           read_b(nxt, slot, s4 + 1);
         } else if (tap < NT - 1) {
@@ -612,129 +624,143 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a, int tilesX
     const unsigned short* resp = reinterpret_cast<const unsigned short*>(a.residual);
 #pragma unroll
     for (int it = 0; it < EPI; ++it) {
-      const int e = tid + it * 256;
+      // piece `it` of this thread: half it / (EPI/EPH), piece tid + 256 * (it % (EPI/EPH)) within the half
+      const int e = (it / (EPI / EPH)) * ((TH / EPH) * 16 * (BN / 8)) + tid + (it % (EPI / EPH)) * 256;
       const int pl = e / (BN / 8), c8 = e % (BN / 8);
       const int oy = oy0 + (pl >> 4), ox = ox0 + (pl & 15);
       const int co = n0 + c8 * 8;
       rres[it] = make_uint4(0, 0, 0, 0);
-      if (resp && !a.head_out && e < TH * 16 * (BN / 8) && oy < a.Ho && ox < a.Wo && co + 8 <= a.Cout &&
-          (a.Cout & 7) == 0)
+      if (resp && !a.head_out && tid + (it % (EPI / EPH)) * 256 < (TH / EPH) * 16 * (BN / 8) && oy < a.Ho &&
+          ox < a.Wo && co + 8 <= a.Cout && (a.Cout & 7) == 0)
         rres[it] = *reinterpret_cast<const uint4*>(resp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + co);
     }
   }
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int cl = wc * 64 + ct * 32 + r;  // channel within the tile
-    const int co = n0 + cl;
-    const bool cok = co < a.Cout;
-    const float sc = esc[ct], sh = esh[ct];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int pl = (prow0 + 2 * rt + (row >> 4)) * 16 + (row & 15);  // pixel within the tile
-        const float raw = acc[rt][ct][i];
-        otile[pl * OLD + cl] = raw * sc + sh;
-        if (a.stats) {
-          const int oy = oy0 + (pl >> 4), ox = ox0 + (pl & 15);
-          if (cok && oy < a.Ho && ox < a.Wo) {
-            s1 += raw;
-            s2 += raw * raw;
-          }
-        }
-      }
-    }
-    if (a.stats) {
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (h == 0 && cok) {
-        atomicAdd(a.stats + co, s1);
-        atomicAdd(a.stats + a.Cout + co, s2);
-      }
-    }
-  }
-  lds_barrier();
-  if (a.head_out) {
-    // fused 1x1 head: the 16 lanes that hold the BN = 128 channels of one pixel reduce
-    // their partial dot products with shuffles; the activation itself is never stored
-    if (BN == 128) {
-      for (int e = tid; e < TH * 16 * 16; e += 256) {
-        const int pl = e >> 4, c8 = e & 15;
-        const int oy = oy0 + (pl >> 4), ox = ox0 + (pl & 15);
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8 + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        if (a.relu) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-        }
-        for (int k = 0; k < a.head_n; ++k) {
-          const float* hw = a.head_w + k * BN + c8 * 8;
-          float part = 0.f;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) part = fmaf(v[j], hw[j], part);
-#pragma unroll
-          for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-          if (c8 == 0 && oy < a.Ho && ox < a.Wo)
-            a.head_out[(((size_t)b * a.head_n + k) * a.Ho + oy) * a.Wo + ox] = part + a.head_b[k];
-        }
-      }
-    }
-    return;
-  }
+  // EPH = 2 (KC = 32): the tile is staged and stored in two halves of TH/2 rows, so the staging
+  // area fits the 39 KB the main loop used (three workgroups per CU)
+  constexpr int HROWS = TH / EPH;                       // image rows per staged half
+  constexpr int HPIECES = HROWS * 16 * (BN / 8);        // 16-B output pieces per half
+  static_assert(EPI % EPH == 0 && HPIECES % 256 == 0 || EPH == 1, "half tiles split evenly over the threads");
   unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
   const unsigned short* res = reinterpret_cast<const unsigned short*>(a.residual);
   const bool vec_ok = (a.Cout & 7) == 0;  // 16-B aligned channel groups
 #pragma unroll
-  for (int it = 0; it < EPI; ++it) {
-    const int e = tid + it * 256;
-    if (e >= TH * 16 * (BN / 8)) continue;
-    const int pl = e / (BN / 8), c8 = e % (BN / 8);
-    const int oy = oy0 + (pl >> 4), ox = ox0 + (pl & 15);
-    const int co = n0 + c8 * 8;
-    if (oy >= a.Ho || ox >= a.Wo || co >= a.Cout) continue;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8 + 4);
-    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
-    if (vec_ok && co + 8 <= a.Cout) {
-      if (res) {
-        const uint4 rv = rres[it];
-        const unsigned int ru[4] = {rv.x, rv.y, rv.z, rv.w};
+  for (int half = 0; half < EPH; ++half) {
+    const bool mine = EPH == 1 || (prow0 / HROWS) == half;  // this wave's rows belong to the half
+    if (mine) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          v[2 * k] += lss_bf2f((unsigned short)(ru[k] & 0xffff));
-          v[2 * k + 1] += lss_bf2f((unsigned short)(ru[k] >> 16));
+      for (int ct = 0; ct < 2; ++ct) {
+        const int cl = wc * 64 + ct * 32 + r;  // channel within the tile
+        const int co = n0 + cl;
+        const bool cok = co < a.Cout;
+        const float sc = esc[ct], sh = esh[ct];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int pl = (prow0 - half * HROWS + 2 * rt + (row >> 4)) * 16 + (row & 15);  // pixel within the half
+            const float raw = acc[rt][ct][i];
+            otile[pl * OLD + cl] = raw * sc + sh;
+            if (a.stats) {
+              const int oy = oy0 + half * HROWS + (pl >> 4), ox = ox0 + (pl & 15);
+              if (cok && oy < a.Ho && ox < a.Wo) {
+                s1 += raw;
+                s2 += raw * raw;
+              }
+            }
+          }
+        }
+        if (a.stats) {
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+          if (h == 0 && cok) {
+            atomicAdd(a.stats + co, s1);
+            atomicAdd(a.stats + a.Cout + co, s2);
+          }
         }
       }
-      if (a.relu == 1) {
+    }
+    lds_barrier();
+    if (a.head_out) {
+      // fused 1x1 head: the 16 lanes that hold the BN = 128 channels of one pixel reduce
+      // their partial dot products with shuffles; the activation itself is never stored
+      if (BN == 128) {
+        for (int e = tid; e < HROWS * 16 * 16; e += 256) {
+          const int pl = e >> 4, c8 = e & 15;
+          const int oy = oy0 + half * HROWS + (pl >> 4), ox = ox0 + (pl & 15);
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8 + 4);
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          if (a.relu) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-      } else if (a.relu == 2) {
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+          }
+          for (int k = 0; k < a.head_n; ++k) {
+            const float* hw = a.head_w + k * BN + c8 * 8;
+            float part = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = conv_act(v[k], 2);
-      }
-      if (a.out_f32) {
-        float* yf = reinterpret_cast<float*>(a.y) + o;
-        *reinterpret_cast<f32x4*>(yf) = (f32x4){v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(yf + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-      } else {
-        uint4 ov;
-        ov.x = lss_pack_bf2(v[0], v[1]); ov.y = lss_pack_bf2(v[2], v[3]);
-        ov.z = lss_pack_bf2(v[4], v[5]); ov.w = lss_pack_bf2(v[6], v[7]);
-        *reinterpret_cast<uint4*>(y + o) = ov;
+            for (int j = 0; j < 8; ++j) part = fmaf(v[j], hw[j], part);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            if (c8 == 0 && oy < a.Ho && ox < a.Wo)
+              a.head_out[(((size_t)b * a.head_n + k) * a.Ho + oy) * a.Wo + ox] = part + a.head_b[k];
+          }
+        }
       }
     } else {
-      for (int k = 0; k < 8 && co + k < a.Cout; ++k) {
-        float t = v[k];
-        if (res) t += lss_bf2f(res[o + k]);
-        t = conv_act(t, a.relu);
-        if (a.out_f32) reinterpret_cast<float*>(a.y)[o + k] = t;
-        else y[o + k] = lss_f2bf(t);
+#pragma unroll
+      for (int j = 0; j < EPI / EPH; ++j) {
+        const int it = half * (EPI / EPH) + j;  // index into the prefetched residual pieces
+        const int e = tid + j * 256;            // piece within the half
+        if (e >= HPIECES) continue;
+        const int pl = e / (BN / 8), c8 = e % (BN / 8);
+        const int oy = oy0 + half * HROWS + (pl >> 4), ox = ox0 + (pl & 15);
+        const int co = n0 + c8 * 8;
+        if (oy >= a.Ho || ox >= a.Wo || co >= a.Cout) continue;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8 + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
+        if (vec_ok && co + 8 <= a.Cout) {
+          if (res) {
+            const uint4 rv = rres[it];
+            const unsigned int ru[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v[2 * k] += lss_bf2f((unsigned short)(ru[k] & 0xffff));
+              v[2 * k + 1] += lss_bf2f((unsigned short)(ru[k] >> 16));
+            }
+          }
+          if (a.relu == 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+          } else if (a.relu == 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = conv_act(v[k], 2);
+          }
+          if (a.out_f32) {
+            float* yf = reinterpret_cast<float*>(a.y) + o;
+            *reinterpret_cast<f32x4*>(yf) = (f32x4){v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(yf + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+          } else {
+            uint4 ov;
+            ov.x = lss_pack_bf2(v[0], v[1]); ov.y = lss_pack_bf2(v[2], v[3]);
+            ov.z = lss_pack_bf2(v[4], v[5]); ov.w = lss_pack_bf2(v[6], v[7]);
+            *reinterpret_cast<uint4*>(y + o) = ov;
+          }
+        } else {
+          for (int k = 0; k < 8 && co + k < a.Cout; ++k) {
+            float t = v[k];
+            if (res) t += lss_bf2f(res[o + k]);
+            t = conv_act(t, a.relu);
+            if (a.out_f32) reinterpret_cast<float*>(a.y)[o + k] = t;
+            else y[o + k] = lss_f2bf(t);
+          }
+        }
       }
     }
+    if (half + 1 < EPH) lds_barrier();  // everyone has read this half before the next one is staged
   }
 }
 
@@ -799,8 +825,24 @@ void launch_conv_lds(const ConvArgs& a, hipStream_t st) {
     if (rt == 2) hipLaunchKernelGGL((conv_lds_kernel<2, 64, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);
     else hipLaunchKernelGGL((conv_lds_kernel<1, 64, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);
   } else {
-    if (rt == 2) hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);
-    else hipLaunchKernelGGL((conv_lds_kernel<1, 128, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    // Half-depth steps, three workgroups per CU.  Measured (same box, B = 4): the fused
+    // upsample/concat convs gain (up1.conv0 100 -> 83 us, up2.1 141 -> 133 us: the third workgroup
+    // fills the synchronous gather phases), the plain 3x3 loses 5 % (half-depth steps double the
+    // barriers per MFMA) - so MODE 1 takes KC = 32 by default, MODE 0 keeps 64 (LSS_CONV_KC overrides).
+    bool kc32 = MODE == 1;
+    if (const char* e = getenv("LSS_CONV_KC")) kc32 = atoi(e) == 32;
+    kc32 = kc32 && MODE != 2 && KH == 3 && rt == 2 && a.Cx % 32 == 0 && a.C2 % 32 == 0;
+    if (rt == 2) {
+      if constexpr (MODE != 2 && KH == 3) {
+        if (kc32) {
+          hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD, 32>), g, dim3(256), 0, st, a, tilesX, tilesY);
+          return;
+        }
+      }
+      hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    } else {
+      hipLaunchKernelGGL((conv_lds_kernel<1, 128, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    }
   }
 }
 
