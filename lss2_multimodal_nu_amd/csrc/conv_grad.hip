@@ -151,9 +151,18 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
     const size_t t = e / Cin;
     const int co = t % Cout;
     const int tap = t / Cout;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * n + e];
-    dw[((size_t)co * Cin + ci) * 9 + tap] = s;
+    // four interleaved partial sums (fixed assignment split k -> accumulator k & 3, fixed final
+    // tree): the loads of a thread are independent, so they pipeline instead of serialising
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {
+      s0 += partial[(size_t)k * n + e];
+      s1 += partial[(size_t)(k + 1) * n + e];
+      s2 += partial[(size_t)(k + 2) * n + e];
+      s3 += partial[(size_t)(k + 3) * n + e];
+    }
+    for (; k < nsplit; ++k) s0 += partial[(size_t)k * n + e];
+    dw[((size_t)co * Cin + ci) * 9 + tap] = (s0 + s1) + (s2 + s3);
   }
 }
 

@@ -5,7 +5,7 @@
 // 1x1 convs around it (ref: src/model_vovnet_transformer.py:131-135, 150).
 //
 // Both operands are K-contiguous, so both are staged by LDS-DMA (no register
-// hop) into a 4-slot ring of 32-channel slabs:
+// hop) into a 3-slot ring of 32-channel slabs:
 //   workgroup 256 threads = 128 rows x 128 columns, wave = 64 x 64 = 2 x 2 tiles
 //   of v_mfma_f32_32x32x16_bf16; one ring slot = 128 x 64 B of x + 128 x 64 B of
 //   w = 16 KiB = 16 DMA blocks of 1 KiB, 4 per wave; slabs are fetched three steps
@@ -13,7 +13,9 @@
 //   64-B rows are XOR-swizzled in 16-B pieces by ((row >> 2) & 3) - on the DMA's
 //   source address (its destination is lane-linear) and on the read address -
 //   which makes every 16-lane group of a ds_read_b128 hit 64 distinct banks.
-//   LDS = max(ring 64 KiB, fp32 output tile 66 KiB) -> 2 workgroups per CU.
+//   A slot is drained into registers one step before its barrier, so the slab three steps ahead
+//   is issued into the slot just consumed: 3 slots, 3 steps of prefetch.  LDS = ring 48 KiB (the fp32
+//   output tile is staged in two 64-row halves of 33 KiB) -> 3 workgroups per CU.
 // Epilogue as in conv_mfma.hip: scale/shift in registers -> fp32 tile in LDS ->
 // 8 consecutive channels per thread, residual / activation / one 16-B (bf16) or
 // 32-B (fp32) store.
@@ -42,15 +44,15 @@ struct LinearArgs {
   const unsigned short* wk[3];
 };
 
-constexpr int BM = 128, BN = 128, BK = 32, NS = 4;
+constexpr int BM = 128, BN = 128, BK = 32, NS = 3;
 constexpr int ROWB = BK * 2;                 // bytes per staged row
 constexpr int OP_BYTES = BM * ROWB;          // 8 KiB per operand and slot
 constexpr int SLOT_BYTES = 2 * OP_BYTES;     // 16 KiB
 constexpr int OLD = BN + 4;                  // fp32 output tile row (padded)
 constexpr int RING_BYTES = NS * SLOT_BYTES;
-constexpr int OUT_BYTES = BM * OLD * 4;
+constexpr int OUT_BYTES = (BM / 2) * OLD * 4;         // the output tile is staged in two 64-row halves
 constexpr int SMEM_BYTES = RING_BYTES > OUT_BYTES ? RING_BYTES : OUT_BYTES;
-static_assert(SMEM_BYTES <= 80 * 1024, "two workgroups per CU");
+static_assert(SMEM_BYTES <= 53 * 1024, "three workgroups per CU");
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -84,7 +86,7 @@ __device__ __forceinline__ float act_fn(float v, int act) {
   return v;
 }
 
-__global__ __launch_bounds__(256, 2) void linear_mfma_kernel(LinearArgs a) {
+__global__ __launch_bounds__(256, 3) void linear_mfma_kernel(LinearArgs a) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(LinearArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // prologue: slabs 0..2 on their way (the whole ring); slab 0 must have landed
   issue(0, 0);
   if (nsteps > 1) issue(1, 1);
   if (nsteps > 2) issue(2, 2);
@@ -172,23 +175,22 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(LinearArgs a) {
   int slot = 0;
   read(0, 0);
   for (int step = 0; step < nsteps; ++step) {
-    const int slot3 = (slot + 3) & 3;
-    const bool more = step + 3 < nsteps;
     read(1, slot);
     __builtin_amdgcn_sched_barrier(0);
-    if (more) issue(step + 3, slot3);  // that slot was last read in step-1: every wave is past its barrier
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
-    // slab step+1 must have landed in every wave's share before anyone reads it; the two
-    // younger slabs stay in flight across the barrier
-    if (more) wait_vmcnt<8>();
-    else if (step + 2 < nsteps) wait_vmcnt<4>();
+    // slab step+1 must have landed in every wave's share before anyone reads it; the younger slab
+    // (step+2) stays in flight across the barrier
+    if (step + 2 < nsteps) wait_vmcnt<4>();
     else wait_vmcnt<0>();
-    lds_barrier();  // (also: every fragment of this slot is in registers)
-    slot = (slot + 1) & 3;
+    lds_barrier();  // (also: every fragment of THIS slot is in registers now, in every wave)
+    // ... so the slot just consumed is free: the slab three steps ahead goes into it (a 3-slot
+    // ring that runs 3 steps ahead)
+    if (step + 3 < nsteps) issue(step + 3, slot);
+    slot = slot == 2 ? 0 : slot + 1;
     if (step + 1 < nsteps) read(0, slot);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -199,72 +201,79 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(LinearArgs a) {
   }
   lds_barrier();  // ring no longer read: reuse it as the fp32 output tile
 
-  // D[row = (e&3) + 8*(e>>2) + 4*h][col = r]: a lane holds one column of 16 rows
+  // D[row = (e&3) + 8*(e>>2) + 4*h][col = r]: a lane holds one column of 16 rows.  The fp32 tile
+  // is staged in two 64-row halves (waves wr = 0, then wr = 1) so it fits the ring's 48 KiB.
   float* otile = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int cl = wc * 64 + j * 32 + r;
-    const int co = n0 + cl;
-    const bool cok = co < a.N;
-    const float sc = (cok && a.scale) ? a.scale[co] : 1.f;
-    const float sh = (cok && a.shift) ? a.shift[co] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        otile[row * OLD + cl] = acc[i][j][e] * sc + sh;
-      }
-  }
-  lds_barrier();
   unsigned short* yb = reinterpret_cast<unsigned short*>(a.y);
   float* yf = ybatch ? ybatch : reinterpret_cast<float*>(a.y);
   const bool vec_ok = (a.N & 7) == 0;
-  for (int e = tid; e < BM * (BN / 8); e += 256) {
-    const int row = e / (BN / 8), c8 = e % (BN / 8);
-    const int m = m0 + row, co = n0 + c8 * 8;
-    if (m >= a.M || co >= a.N) continue;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(otile + row * OLD + c8 * 8);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(otile + row * OLD + c8 * 8 + 4);
-    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    const size_t o = (size_t)m * a.N + co;  // residual (and row-major output) index
-    size_t oy = o;
-    if (a.group_hw > 0) {
-      const int bidx = m / a.group_hw, pix = m - bidx * a.group_hw;
-      oy = (((size_t)bidx * (a.N >> 5) + (co >> 5)) * a.group_hw + pix) * 32 + (co & 31);
-    }
-    if (vec_ok && co + 8 <= a.N) {
-      if (a.residual) {
-        const uint4 rv = *reinterpret_cast<const uint4*>(a.residual + o);
-        const unsigned int ru[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          v[2 * k] += lss_bf2f((unsigned short)(ru[k] & 0xffff));
-          v[2 * k + 1] += lss_bf2f((unsigned short)(ru[k] >> 16));
+  for (int half = 0; half < 2; ++half) {
+    if (wr == half) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cl = wc * 64 + j * 32 + r;
+        const int co = n0 + cl;
+        const bool cok = co < a.N;
+        const float sc = (cok && a.scale) ? a.scale[co] : 1.f;
+        const float sh = (cok && a.shift) ? a.shift[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;  // row within the half
+            otile[row * OLD + cl] = acc[i][j][e] * sc + sh;
+          }
+      }
+    }
+    lds_barrier();
+    for (int e = tid; e < (BM / 2) * (BN / 8); e += 256) {
+      const int row = e / (BN / 8), c8 = e % (BN / 8);
+      const int m = m0 + half * (BM / 2) + row, co = n0 + c8 * 8;
+      if (m >= a.M || co >= a.N) continue;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(otile + row * OLD + c8 * 8);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(otile + row * OLD + c8 * 8 + 4);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      const size_t o = (size_t)m * a.N + co;  // residual (and row-major output) index
+      size_t oy = o;
+      if (a.group_hw > 0) {
+        const int bidx = m / a.group_hw, pix = m - bidx * a.group_hw;
+        oy = (((size_t)bidx * (a.N >> 5) + (co >> 5)) * a.group_hw + pix) * 32 + (co & 31);
+      }
+      if (vec_ok && co + 8 <= a.N) {
+        if (a.residual) {
+          const uint4 rv = *reinterpret_cast<const uint4*>(a.residual + o);
+          const unsigned int ru[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[2 * k] += lss_bf2f((unsigned short)(ru[k] & 0xffff));
+            v[2 * k + 1] += lss_bf2f((unsigned short)(ru[k] >> 16));
+          }
+        }
+        if (a.act) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = act_fn(v[k], a.act);
+        }
+        if (a.out_f32) {
+          *reinterpret_cast<f32x4*>(yf + oy) = (f32x4){v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(yf + oy + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        } else {
+          uint4 ov;
+          ov.x = lss_pack_bf2(v[0], v[1]); ov.y = lss_pack_bf2(v[2], v[3]);
+          ov.z = lss_pack_bf2(v[4], v[5]); ov.w = lss_pack_bf2(v[6], v[7]);
+          *reinterpret_cast<uint4*>(yb + oy) = ov;
+        }
+      } else {
+        for (int k = 0; k < 8 && co + k < a.N; ++k) {
+          float tv = v[k];
+          if (a.residual) tv += lss_bf2f(a.residual[o + k]);
+          tv = act_fn(tv, a.act);
+          if (a.out_f32) yf[oy + k] = tv;
+          else yb[oy + k] = lss_f2bf(tv);
         }
       }
-      if (a.act) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = act_fn(v[k], a.act);
-      }
-      if (a.out_f32) {
-        *reinterpret_cast<f32x4*>(yf + oy) = (f32x4){v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(yf + oy + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-      } else {
-        uint4 ov;
-        ov.x = lss_pack_bf2(v[0], v[1]); ov.y = lss_pack_bf2(v[2], v[3]);
-        ov.z = lss_pack_bf2(v[4], v[5]); ov.w = lss_pack_bf2(v[6], v[7]);
-        *reinterpret_cast<uint4*>(yb + oy) = ov;
-      }
-    } else {
-      for (int k = 0; k < 8 && co + k < a.N; ++k) {
-        float tv = v[k];
-        if (a.residual) tv += lss_bf2f(a.residual[o + k]);
-        tv = act_fn(tv, a.act);
-        if (a.out_f32) yf[oy + k] = tv;
-        else yb[oy + k] = lss_f2bf(tv);
-      }
     }
+    if (half == 0) lds_barrier();  // everyone has read half 0 before half 1 is staged
   }
 }
 
