@@ -43,6 +43,7 @@ struct ConvArgs {
   int Ho, Wo, M;
   int relu;     // activation: 0 none, 1 ReLU, 2 GELU (erf form)
   int out_f32;  // bf16 kernels: write y as fp32
+  int wt;       // epilogue stores write through (sc1): nothing left dirty in L2 at the kernel boundary
   float ry, rx;  // (H-1)/(Hin-1), (W-1)/(Win-1) for the align_corners upsample
   // optional fused 1x1 head (ref: src/modules.py:115 up2[4]): out[b,k,oy,ox] =
   // head_b[k] + sum_co act(...)[co] * head_w[k, co]; NCHW fp32; needs Cout == BN
@@ -312,8 +313,16 @@ __device__ __forceinline__ void wait_vmcnt() {
 // RT = 32-pixel MFMA row tiles per wave (2: 4 image rows x 64 channels per wave, the
 // throughput shape; 1: 2 image rows, half the work per workgroup - used when the RT = 2
 // grid would leave CUs idle, where the per-workgroup critical path is what counts).
-template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64>
-__global__ __launch_bounds__(256, KC == 32 ? 3 : 2) void conv_lds_kernel(ConvArgs a, int tilesX, int tilesY) {
+template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64, int KSP = 1>
+__global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void conv_lds_kernel(ConvArgs a, int tilesX,
+                                                                                             int tilesY) {
+  // KSP = 2: intra-workgroup split-K for grids that cannot fill the chip (layer2/layer3: 112-208
+  // workgroups of 18-36 latency-bound steps on 256 CUs).  512 threads = two 4-wave groups, each
+  // with its own weight ring and patch, each taking half of the input-channel chunks; the second
+  // group's accumulators meet the first's through LDS before the (unchanged) epilogue.  Halves
+  // the main loop at the same workgroup count; barriers stay workgroup-wide (both groups run the
+  // same step sequence).
+  static_assert(KSP == 1 || (KSP == 2 && KC == 64), "KSP");
   // KC = input channels per (chunk, tap) step.  64: the default.  32: half-depth slabs and patch
   // (39 KB of LDS, <= 168 VGPRs) so THREE workgroups share a CU - used for the big stride-1 layers,
   // whose 728 / 1300 tiles then run in one / two full rounds instead of 1.4 / 2.5 on 512 slots.
@@ -335,14 +344,16 @@ __global__ __launch_bounds__(256, KC == 32 ? 3 : 2) void conv_lds_kernel(ConvArg
   // the epilogue stages the fp32 output tile in LDS: whole (KC = 64) or in two halves of TH/2 rows
   constexpr int EPH = KC == 32 ? 2 : 1;
   constexpr int OUT_BYTES = (TH / EPH) * 16 * OLD * 4;
-  constexpr int SMEM_BYTES = (3 * W_BYTES + IN_BYTES) > OUT_BYTES ? (3 * W_BYTES + IN_BYTES) : OUT_BYTES;
-  static_assert(SMEM_BYTES <= (KC == 32 ? 53 : 80) * 1024, "two (three) workgroups must fit one CU's 160 KiB of LDS");
+  constexpr int GROUP_BYTES = (3 * W_BYTES + IN_BYTES + 1023) / 1024 * 1024;  // ring + patch of one 4-wave group
+  constexpr int SMEM_BYTES = KSP * GROUP_BYTES > OUT_BYTES ? KSP * GROUP_BYTES : OUT_BYTES;
+  static_assert(SMEM_BYTES <= (KSP == 2 ? 160 : (KC == 32 ? 53 : 80)) * 1024, "workgroups per CU vs 160 KiB of LDS");
   static_assert(KC == 64 || (RT == 2 && BN == 128 && MODE != 2), "KC = 32 is built for the RT = 2, BN = 128 stride-1 tiles");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
-  unsigned char* w_tile = smem;
-  unsigned char* in_tile = smem + 3 * W_BYTES;
+  const int grp = KSP == 2 ? (int)(threadIdx.x >> 8) : 0;  // K-split group of this wave
+  unsigned char* w_tile = smem + grp * GROUP_BYTES;
+  unsigned char* in_tile = w_tile + 3 * W_BYTES;
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x & 255, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   // XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin to
@@ -382,12 +393,14 @@ __global__ __launch_bounds__(256, KC == 32 ? 3 : 2) void conv_lds_kernel(ConvArg
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const unsigned short* wg = reinterpret_cast<const unsigned short*>(a.w);
-  const int nsteps = (a.Cin / KC) * NT;
+  const int nchunks = a.Cin / KC / KSP;  // K chunks of this group
+  const int cbase = grp * nchunks;        // first chunk of this group
+  const int nsteps = nchunks * NT;
   uint4 ireg[IPT];
   // weight slab of `step` -> ring slot: lane l of DMA block k lands at byte k*1024 + l*16,
   // i.e. row 8k + (l >> 3), 16-B slot l & 7, which must hold channel piece slot ^ swz(row)
   auto issue_w = [&](int step, int slot) {
-    const int tap = step % NT, chunk = step / NT;
+    const int tap = step % NT, chunk = cbase + step / NT;
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       const int blk = i * 4 + wave;
@@ -433,7 +446,7 @@ __global__ __launch_bounds__(256, KC == 32 ? 3 : 2) void conv_lds_kernel(ConvArg
   auto gather_fused = [&](int chunk) {
     const unsigned short* xp = reinterpret_cast<const unsigned short*>(a.x);
     const unsigned short* x2p = reinterpret_cast<const unsigned short*>(a.x2);
-    const int c0 = chunk * KC;
+    const int c0 = (cbase + chunk) * KC;
     const bool skip = c0 < a.C2;  // chunk of the skip tensor x2: plain copy
     const int dxs = a.Cx, dys = a.W * a.Cx;
 #pragma unroll 2
@@ -474,7 +487,7 @@ __global__ __launch_bounds__(256, KC == 32 ? 3 : 2) void conv_lds_kernel(ConvArg
         const int iy = oy0 - PAD + py, ix = ox0 - PAD + px;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
-          v = load_in_piece<unsigned short, true>(a, b, iy, ix, chunk * KC + part * 8);
+          v = load_in_piece<unsigned short, true>(a, b, iy, ix, (cbase + chunk) * KC + part * 8);
         *reinterpret_cast<uint4*>(in_tile + py * IROWB + px * POSB + part * 16) = v;
       }
     } else {
@@ -485,11 +498,11 @@ __global__ __launch_bounds__(256, KC == 32 ? 3 : 2) void conv_lds_kernel(ConvArg
         if (q < IH * IW * PPP) {
           const int pos = q >> PSH, part = q & (PPP - 1);
           const int py = pos / IW, px = pos - py * IW;
-          int iy = oy0 - PAD + py, ix = ox0 - PAD + px, cc = chunk;
+          int iy = oy0 - PAD + py, ix = ox0 - PAD + px, cc = cbase + chunk;
           if (MODE == 2) {  // (iy, ix) are phase-plane coordinates; chunk -> (phase, channel block)
             const int nblk = a.Cx / KC;
-            const int ph = chunk / nblk;
-            cc = chunk - ph * nblk;
+            const int ph = cc / nblk;
+            cc = cc - ph * nblk;
             iy = 2 * iy + (ph >> 1);
             ix = 2 * ix + (ph & 1);
           }
@@ -519,10 +532,9 @@ __global__ __launch_bounds__(256, KC == 32 ? 3 : 2) void conv_lds_kernel(ConvArg
     const int row = KC == 64 ? blk * 8 + (lane >> 3) : blk * 16 + (lane >> 2);
     const int part = KC == 64 ? (lane & 7) ^ ((row >> 1) & 7) : (lane & 3) ^ ((row >> 2) & 3);
     const int co = min(n0 + row, a.Cout - 1);
-    glds16(wg + ((size_t)tap * a.Cout + co) * a.Cin + chunk * KC + part * 8,
+    glds16(wg + ((size_t)tap * a.Cout + co) * a.Cin + (cbase + chunk) * KC + part * 8,
            w_tile + slot * W_BYTES + blk * 1024);
   };
-  const int nchunks = a.Cin / KC;
 
   // per-lane epilogue constants, fetched now so their latency is long gone by the epilogue
   float esc[2], esh[2];
@@ -616,6 +628,34 @@ __global__ __launch_bounds__(256, KC == 32 ? 3 : 2) void conv_lds_kernel(ConvArg
   // residual (one 16-B load), ReLU, rounds to bf16 once, and stores 16 B.
   float* otile = reinterpret_cast<float*>(smem);
   // (the loop's final lds_barrier already guarantees every wave is done reading LDS)
+  if (KSP == 2) {
+    // split-K: the second group's partial sums meet the first group's through LDS (same lane ->
+    // same element in both groups, so only the group hand-over needs barriers)
+    if (grp == 1) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            otile[((prow0 + 2 * rt + (row >> 4)) * 16 + (row & 15)) * OLD + wc * 64 + ct * 32 + r] = acc[rt][ct][i];
+          }
+    }
+    lds_barrier();
+    if (grp == 0) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            acc[rt][ct][i] += otile[((prow0 + 2 * rt + (row >> 4)) * 16 + (row & 15)) * OLD + wc * 64 + ct * 32 + r];
+          }
+    }
+    lds_barrier();  // the partials are consumed before group 0 restages the tile below
+  }
   // residual rows of this thread's output pieces: issued BEFORE the accumulators are staged, so
   // the loads fly during the LDS write / barrier / read-back instead of stalling the store loop
   constexpr int EPI = (TH * 16 * (BN / 8) + 255) / 256;
@@ -630,7 +670,7 @@ __global__ __launch_bounds__(256, KC == 32 ? 3 : 2) void conv_lds_kernel(ConvArg
       const int oy = oy0 + (pl >> 4), ox = ox0 + (pl & 15);
       const int co = n0 + c8 * 8;
       rres[it] = make_uint4(0, 0, 0, 0);
-      if (resp && !a.head_out && tid + (it % (EPI / EPH)) * 256 < (TH / EPH) * 16 * (BN / 8) && oy < a.Ho &&
+      if (grp == 0 && resp && !a.head_out && tid + (it % (EPI / EPH)) * 256 < (TH / EPH) * 16 * (BN / 8) && oy < a.Ho &&
           ox < a.Wo && co + 8 <= a.Cout && (a.Cout & 7) == 0)
         rres[it] = *reinterpret_cast<const uint4*>(resp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + co);
     }
@@ -643,9 +683,11 @@ __global__ __launch_bounds__(256, KC == 32 ? 3 : 2) void conv_lds_kernel(ConvArg
   unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
   const unsigned short* res = reinterpret_cast<const unsigned short*>(a.residual);
   const bool vec_ok = (a.Cout & 7) == 0;  // 16-B aligned channel groups
+  const __amdgpu_buffer_rsrc_t yrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.wt ? (int)((size_t)a.M * a.Cout * 2) : 0, 0x00020000);
 #pragma unroll
   for (int half = 0; half < EPH; ++half) {
-    const bool mine = EPH == 1 || (prow0 / HROWS) == half;  // this wave's rows belong to the half
+    const bool mine = grp == 0 && (EPH == 1 || (prow0 / HROWS) == half);  // this wave's rows belong to the half
     if (mine) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
@@ -682,7 +724,9 @@ __global__ __launch_bounds__(256, KC == 32 ? 3 : 2) void conv_lds_kernel(ConvArg
       }
     }
     lds_barrier();
-    if (a.head_out) {
+    if (grp != 0) {
+      // second K-split group: its sums were handed over above; it only keeps the barriers company
+    } else if (a.head_out) {
       // fused 1x1 head: the 16 lanes that hold the BN = 128 channels of one pixel reduce
       // their partial dot products with shuffles; the activation itself is never stored
       if (BN == 128) {
@@ -747,7 +791,14 @@ __global__ __launch_bounds__(256, KC == 32 ? 3 : 2) void conv_lds_kernel(ConvArg
             uint4 ov;
             ov.x = lss_pack_bf2(v[0], v[1]); ov.y = lss_pack_bf2(v[2], v[3]);
             ov.z = lss_pack_bf2(v[4], v[5]); ov.w = lss_pack_bf2(v[6], v[7]);
-            *reinterpret_cast<uint4*>(y + o) = ov;
+            if (a.wt) {
+              // write-through (sc1) 16-B store: a dependent kernel boundary otherwise pays
+              // (dirty bytes / 6 TB/s) for the L2 write-back (MI355X_MICROARCH.md, row 'boundary')
+              typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+              __builtin_amdgcn_raw_buffer_store_b128((u32x4){ov.x, ov.y, ov.z, ov.w}, yrsrc, (int)(o * 2), 0, 16);
+            } else {
+              *reinterpret_cast<uint4*>(y + o) = ov;
+            }
           }
         } else {
           for (int k = 0; k < 8 && co + k < a.Cout; ++k) {
@@ -841,6 +892,17 @@ void launch_conv_lds(const ConvArgs& a, hipStream_t st) {
       }
       hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);
     } else {
+      // Grids that cannot even give every CU one workgroup (layer2 / layer3 at batch 4): split the
+      // K loop over two 4-wave groups inside the workgroup - half the latency-bound steps each.
+      const long long nwg1 = (long long)g.x * g.y;
+      bool ksplit = MODE != 1 && nwg1 <= 256 && (a.Cin / 64) % 2 == 0 && a.Cin >= 128;
+      if (const char* e = getenv("LSS_CONV_KSPLIT")) ksplit = ksplit && atoi(e) != 0;
+      if constexpr (MODE != 1) {
+        if (ksplit) {
+          hipLaunchKernelGGL((conv_lds_kernel<1, 128, MODE, KH, KW, PAD, 64, 2>), g, dim3(512), 0, st, a, tilesX, tilesY);
+          return;
+        }
+      }
       hipLaunchKernelGGL((conv_lds_kernel<1, 128, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);
     }
   }
@@ -918,6 +980,8 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   a.M = (int)M;
   a.relu = relu & 3;
   a.out_f32 = (relu & LSS_OUT_F32) != 0;
+  a.wt = (getenv("LSS_CONV_WT") == nullptr || atoi(getenv("LSS_CONV_WT")) != 0) &&
+         (unsigned long long)a.M * a.Cout * 2 < (1ULL << 31);
   const bool head_major = (relu & LSS_OUT_HEAD_MAJOR32) != 0;
   if (a.relu == 3 || (relu & ~(3 | LSS_OUT_F32 | LSS_OUT_HEAD_MAJOR32)) != 0) return LSS_E_LAYOUT;
   a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0;
@@ -979,6 +1043,8 @@ extern "C" int lss_conv2d_s2_fwd(const void* x, const void* w_s2d, const float* 
   a.M = (int)M;
   a.relu = relu & 3;
   a.out_f32 = 0;
+  a.wt = (getenv("LSS_CONV_WT") == nullptr || atoi(getenv("LSS_CONV_WT")) != 0) &&
+         (unsigned long long)a.M * a.Cout * 2 < (1ULL << 31);
   a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0;
   a.ry = a.rx = 0.f;
   hipStream_t st = lss_stream(stream);
@@ -1014,6 +1080,8 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
   a.M = (int)M;
   a.relu = relu & 3;
   a.out_f32 = 0;
+  a.wt = (getenv("LSS_CONV_WT") == nullptr || atoi(getenv("LSS_CONV_WT")) != 0) &&
+         (unsigned long long)a.M * a.Cout * 2 < (1ULL << 31);
   a.head_w = head_w; a.head_b = head_b; a.head_out = out; a.head_n = head_n;
   a.ry = a.Hin > 1 ? (float)(H - 1) / (float)(a.Hin - 1) : 0.f;
   a.rx = a.Win > 1 ? (float)(W - 1) / (float)(a.Win - 1) : 0.f;
