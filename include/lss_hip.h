@@ -365,6 +365,15 @@ int lss_conv2d_s2_fwd(const void* x, const void* w_s2d, const float* scale, cons
                       const void* residual, void* y, float* stats, int B, int H, int W, int Cx,
                       int Cout, int K, int pad, int relu, void* stream);
 
+/* Two stride-2 convs over the same input in one launch (K = 3, pad 1): w_s2d / scale / shift hold
+ * Cout = split + rest output channels; channels [0, split) -> y (B,Ho,Wo,split) with the activation,
+ * [split, Cout) -> y2 (B,Ho,Wo,Cout-split) without.  split % 128 == 0.
+ * replaces: torchvision BasicBlock.forward's `relu(bn1(conv1(x)))` and `downsample(x)` of layer2.0 /
+ * layer3.0 (the 1x1/2 downsample weight sits at the centre tap of a 3x3 frame in w_s2d). */
+int lss_conv2d_s2_dual_fwd(const void* x, const void* w_s2d, const float* scale, const float* shift,
+                           void* y, void* y2, int B, int H, int W, int Cx, int Cout, int split, int K,
+                           int pad, int relu, void* stream);
+
 /* 3x3/s1/p1 conv (+ fused upsample/concat gather) + scale/shift + ReLU + fused 1x1
  * head, bf16 in, NCHW fp32 out (B, head_n, H*up, W*up).  Cout must be 128.
  * replaces: src/modules.py:110-116 (up2: upsample, conv3x3, BN, ReLU, conv1x1+bias)
@@ -384,9 +393,10 @@ typedef struct lss_conv_launch {
   const void* x; const void* x2; const void* w; const float* scale; const float* shift;
   const void* residual; void* y; float* stats;
   const float* head_w; const float* head_b; float* head_out;   /* kind 2 only */
+  void* y2;                                                     /* kind 3 only */
   int32_t B, H, W, Cx, C2, up, Cout, KH, KW, stride, pad, relu, dt, head_n;
-  int32_t kind;   /* 0 = lss_conv2d_fwd, 1 = lss_conv2d_s2_fwd, 2 = lss_conv2d_head_fwd */
-  int32_t reserved;
+  int32_t kind;   /* 0 = lss_conv2d_fwd, 1 = lss_conv2d_s2_fwd, 2 = lss_conv2d_head_fwd, 3 = lss_conv2d_s2_dual_fwd */
+  int32_t split;  /* kind 3 only */
 } lss_conv_launch_t;
 /* Enqueue `n` conv launches in order on `stream`; returns the first non-zero code. */
 int lss_conv2d_sequence(const lss_conv_launch_t* launches, int n, void* stream);

@@ -55,6 +55,7 @@ SIGNATURES = {
     "lss_conv2d_pack_weights_s2d": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "lss_conv2d_s2_fwd": (_i, [_vp] * 7 + [_i] * 8 + [_vp]),
     "lss_conv2d_head_fwd": (_i, [_vp] * 8 + [_i] * 9 + [_vp]),
+    "lss_conv2d_s2_dual_fwd": (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
     "lss_conv2d_sequence": (_i, [_vp, _i, _vp]),
     "lss_lift_splat_forward": (_i, [_vp] * 10 + [_i] * 10 + [_vp] * 8 + [_i, _i, _vp]),
     "lss_nchw_f32_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -66,9 +67,9 @@ SIGNATURES = {
 class ConvLaunch(ctypes.Structure):
     """lss_conv_launch_t of include/lss_hip.h."""
     _fields_ = [(n, _vp) for n in ("x", "x2", "w", "scale", "shift", "residual", "y", "stats",
-                                   "head_w", "head_b", "head_out")] + \
+                                   "head_w", "head_b", "head_out", "y2")] + \
                [(n, ctypes.c_int32) for n in ("B", "H", "W", "Cx", "C2", "up", "Cout", "KH", "KW", "stride", "pad",
-                                              "relu", "dt", "head_n", "kind", "reserved")]
+                                              "relu", "dt", "head_n", "kind", "split")]
 
 
 _lib = None

@@ -44,6 +44,11 @@ struct ConvArgs {
   int relu;     // activation: 0 none, 1 ReLU, 2 GELU (erf form)
   int out_f32;  // bf16 kernels: write y as fp32
   int wt;       // epilogue stores write through (sc1): nothing left dirty in L2 at the kernel boundary
+  // two convs over the same input in one launch (a BasicBlock's stride-2 conv1 and its 1x1
+  // downsample): output channels [0, split) go to y, [split, Cout) to y2, each dense; the
+  // activation applies to channels below relu_n only.  split, relu_n are multiples of the 128-wide tile.
+  void* y2;
+  int split, relu_n;
   float ry, rx;  // (H-1)/(Hin-1), (W-1)/(Win-1) for the align_corners upsample
   // optional fused 1x1 head (ref: src/modules.py:115 up2[4]): out[b,k,oy,ox] =
   // head_b[k] + sum_co act(...)[co] * head_w[k, co]; NCHW fp32; needs Cout == BN
@@ -680,11 +685,16 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
   constexpr int HROWS = TH / EPH;                       // image rows per staged half
   constexpr int HPIECES = HROWS * 16 * (BN / 8);        // 16-B output pieces per half
   static_assert(EPI % EPH == 0 && HPIECES % 256 == 0 || EPH == 1, "half tiles split evenly over the threads");
-  unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
+  // dual-output launches: this workgroup's channel block belongs to y (columns [0, split)) or y2
+  const bool second = a.y2 != nullptr && n0 >= a.split;
+  const int ycol0 = second ? a.split : 0;                                   // first channel of the tensor
+  const int ycw = a.y2 == nullptr ? a.Cout : (second ? a.Cout - a.split : a.split);  // its channel count
+  const int eact = n0 < a.relu_n ? a.relu : 0;
+  unsigned short* y = reinterpret_cast<unsigned short*>(second ? a.y2 : a.y);
   const unsigned short* res = reinterpret_cast<const unsigned short*>(a.residual);
-  const bool vec_ok = (a.Cout & 7) == 0;  // 16-B aligned channel groups
+  const bool vec_ok = (ycw & 7) == 0;  // 16-B aligned channel groups
   const __amdgpu_buffer_rsrc_t yrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.wt ? (int)((size_t)a.M * a.Cout * 2) : 0, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(y, 0, a.wt ? (int)((size_t)a.M * ycw * 2) : 0, 0x00020000);
 #pragma unroll
   for (int half = 0; half < EPH; ++half) {
     const bool mine = grp == 0 && (EPH == 1 || (prow0 / HROWS) == half);  // this wave's rows belong to the half
@@ -765,7 +775,7 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8 + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
+        const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ycw + (co - ycol0);
         if (vec_ok && co + 8 <= a.Cout) {
           if (res) {
             const uint4 rv = rres[it];
@@ -776,10 +786,10 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
               v[2 * k + 1] += lss_bf2f((unsigned short)(ru[k] >> 16));
             }
           }
-          if (a.relu == 1) {
+          if (eact == 1) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-          } else if (a.relu == 2) {
+          } else if (eact == 2) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = conv_act(v[k], 2);
           }
@@ -804,7 +814,7 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
           for (int k = 0; k < 8 && co + k < a.Cout; ++k) {
             float t = v[k];
             if (res) t += lss_bf2f(res[o + k]);
-            t = conv_act(t, a.relu);
+            t = conv_act(t, eact);
             if (a.out_f32) reinterpret_cast<float*>(a.y)[o + k] = t;
             else y[o + k] = lss_f2bf(t);
           }
@@ -982,6 +992,7 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   a.out_f32 = (relu & LSS_OUT_F32) != 0;
   a.wt = (getenv("LSS_CONV_WT") == nullptr || atoi(getenv("LSS_CONV_WT")) != 0) &&
          (unsigned long long)a.M * a.Cout * 2 < (1ULL << 31);
+  a.y2 = nullptr; a.split = 0; a.relu_n = a.Cout;
   const bool head_major = (relu & LSS_OUT_HEAD_MAJOR32) != 0;
   if (a.relu == 3 || (relu & ~(3 | LSS_OUT_F32 | LSS_OUT_HEAD_MAJOR32)) != 0) return LSS_E_LAYOUT;
   a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0;
@@ -1019,10 +1030,9 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
 
 // Stride-2 k x k conv (k = 3 pad 1, or k = 7 pad 3) on the LDS-tiled kernel through
 // the phase-plane (space-to-depth) form; `w_s2d` from lss_conv2d_pack_weights_s2d.
-extern "C" int lss_conv2d_s2_fwd(const void* x, const void* w_s2d, const float* scale,
-                                 const float* shift, const void* residual, void* y, float* stats,
-                                 int B, int H, int W, int Cx, int Cout, int K, int pad, int relu,
-                                 void* stream) {
+static int conv2d_s2_impl(const void* x, const void* w_s2d, const float* scale, const float* shift,
+                          const void* residual, void* y, float* stats, int B, int H, int W, int Cx, int Cout,
+                          int K, int pad, int relu, void* y2, int split, int relu_n, void* stream) {
   LSS_CHECK_PTR(x); LSS_CHECK_PTR(w_s2d); LSS_CHECK_PTR(y);
   LSS_CHECK_POS(B); LSS_CHECK_POS(H); LSS_CHECK_POS(W); LSS_CHECK_POS(Cx); LSS_CHECK_POS(Cout);
   if (!((K == 3 && pad == 1) || (K == 7 && pad == 3) || (K == 1 && pad == 0))) return LSS_E_SHAPE;
@@ -1045,6 +1055,7 @@ extern "C" int lss_conv2d_s2_fwd(const void* x, const void* w_s2d, const float* 
   a.out_f32 = 0;
   a.wt = (getenv("LSS_CONV_WT") == nullptr || atoi(getenv("LSS_CONV_WT")) != 0) &&
          (unsigned long long)a.M * a.Cout * 2 < (1ULL << 31);
+  a.y2 = y2; a.split = split; a.relu_n = y2 ? relu_n : a.Cout;
   a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0;
   a.ry = a.rx = 0.f;
   hipStream_t st = lss_stream(stream);
@@ -1052,6 +1063,28 @@ extern "C" int lss_conv2d_s2_fwd(const void* x, const void* w_s2d, const float* 
   else if (K == 3) launch_conv_lds<2, 2, 2, 1>(a, st);
   else launch_conv_lds<2, 1, 1, 0>(a, st);
   return lss_launch_status();
+}
+
+extern "C" int lss_conv2d_s2_fwd(const void* x, const void* w_s2d, const float* scale,
+                                 const float* shift, const void* residual, void* y, float* stats,
+                                 int B, int H, int W, int Cx, int Cout, int K, int pad, int relu,
+                                 void* stream) {
+  return conv2d_s2_impl(x, w_s2d, scale, shift, residual, y, stats, B, H, W, Cx, Cout, K, pad, relu, nullptr, 0, 0,
+                        stream);
+}
+
+// Two stride-2 convs over the same input in ONE launch: output channels [0, split) -> y (with the
+// activation), [split, Cout) -> y2 (no activation).  A BasicBlock's 3x3/2 conv1 and its 1x1/2
+// downsample (embedded at the centre tap of a 3x3 frame so both share the phase-plane weight
+// layout; ref: torchvision BasicBlock.forward, `out = relu(bn1(conv1(x)))`, `identity =
+// downsample(x)`): the downsample's own launch (8.5 us) and its kernel boundary disappear.
+extern "C" int lss_conv2d_s2_dual_fwd(const void* x, const void* w_s2d, const float* scale, const float* shift,
+                                      void* y, void* y2, int B, int H, int W, int Cx, int Cout, int split, int K,
+                                      int pad, int relu, void* stream) {
+  LSS_CHECK_PTR(y2);
+  if (split <= 0 || split >= Cout || split % 128 != 0 || (Cout - split) % 8 != 0) return LSS_E_SHAPE;
+  return conv2d_s2_impl(x, w_s2d, scale, shift, nullptr, y, nullptr, B, H, W, Cx, Cout, K, pad, relu, y2, split,
+                        split, stream);
 }
 
 // 3x3 / stride 1 / pad 1 conv (optionally with the fused upsample / concat gather)
@@ -1082,6 +1115,7 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
   a.out_f32 = 0;
   a.wt = (getenv("LSS_CONV_WT") == nullptr || atoi(getenv("LSS_CONV_WT")) != 0) &&
          (unsigned long long)a.M * a.Cout * 2 < (1ULL << 31);
+  a.y2 = nullptr; a.split = 0; a.relu_n = a.Cout;
   a.head_w = head_w; a.head_b = head_b; a.head_out = out; a.head_n = head_n;
   a.ry = a.Hin > 1 ? (float)(H - 1) / (float)(a.Hin - 1) : 0.f;
   a.rx = a.Win > 1 ? (float)(W - 1) / (float)(a.Win - 1) : 0.f;
@@ -1109,6 +1143,9 @@ extern "C" int lss_conv2d_sequence(const lss_conv_launch_t* L, int n, void* stre
     else if (c.kind == 2)
       rc = lss_conv2d_head_fwd(c.x, c.x2, c.w, c.scale, c.shift, c.head_w, c.head_b, c.head_out, c.B, c.H,
                                c.W, c.Cx, c.C2, c.up, c.Cout, c.head_n, c.relu, stream);
+    else if (c.kind == 3)
+      rc = lss_conv2d_s2_dual_fwd(c.x, c.w, c.scale, c.shift, c.y, c.y2, c.B, c.H, c.W, c.Cx, c.Cout, c.split, c.KH,
+                                  c.pad, c.relu, stream);
     else
       rc = LSS_E_LAYOUT;
     if (rc != 0) return rc;

@@ -481,7 +481,30 @@ class BasicBlock(nn.Module):
         out = _train_conv_bn_act(self.conv1, self.bn1, x, relu=True)
         return _train_conv_bn_act(self.conv2, self.bn2, out, relu=True, residual=idt)
 
+    def _dual(self, dt):
+        """conv1 (3x3/2) and the 1x1/2 downsample as ONE launch: both weight sets in the phase-plane layout
+        (the 1x1 weight sits at the centre tap of a 3x3 frame), stacked along Cout; rebuilt when a source changes."""
+        key = self._f1._key(dt) + self._fd._key(dt)
+        if getattr(self, "_dual_key", None) != key:
+            with torch.no_grad():
+                w1, s1, b1 = self._f1.get(dt)
+                _, sd, bd = self._fd.get(dt)
+                wd = self.downsample[0].weight.detach().float()
+                frame = wd.new_zeros(wd.shape[0], wd.shape[1], 3, 3)
+                frame[:, :, 1, 1] = wd[:, :, 0, 0]
+                self._dual_pack = (torch.cat([w1, ops.pack_conv_weight_s2d(frame.contiguous(), 1)], 1).contiguous(),
+                                   torch.cat([s1, sd]).contiguous(), torch.cat([b1, bd]).contiguous())
+            self._dual_key = key
+        return self._dual_pack
+
     def _nhwc(self, x, dt):
+        c1 = self.conv1
+        if (self._fd is not None and dt == ops.DT_BF16 and c1.stride == (2, 2) and self._f1._s2d(dt)
+                and self.downsample[0].stride == (2, 2) and c1.out_channels % 128 == 0
+                and os.environ.get("LSS_NO_DUAL") is None):
+            w, scale, shift = self._dual(dt)
+            t, idt = ops.conv2d_s2_dual_nhwc(x, w, scale, shift, c1.out_channels, relu=True)
+            return self._f2.run(t, dt, relu=True, residual=idt)
         idt = x if self._fd is None else self._fd.run(x, dt, relu=False)
         t = self._f1.run(x, dt, relu=True)
         return self._f2.run(t, dt, relu=True, residual=idt)

@@ -726,6 +726,29 @@ def conv2d_s2_nhwc(x, w_s2d, K, pad, scale=None, shift=None, residual=None, relu
     return y
 
 
+def conv2d_s2_dual_nhwc(x, w_s2d, scale, shift, split, relu=True, tag="conv2d_fwd"):
+    """Two 3x3/2 (pad 1) convs over the same bf16 NHWC input in one launch: w_s2d (taps, Cout, 4*Cx) holds
+    both weight sets stacked along Cout; channels [0, split) -> y (activation applied), the rest -> y2."""
+    B, H, W, Cx = x.shape
+    taps, Cout, C4 = w_s2d.shape
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or w_s2d.dtype != torch.bfloat16 or C4 != 4 * Cx:
+        raise ValueError("conv2d_s2_dual_nhwc operands must be contiguous bf16 with s2d-packed weights")
+    _f32c(scale, "scale", (Cout,))
+    _f32c(shift, "shift", (Cout,))
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty(B, Ho, Wo, split, dtype=torch.bfloat16, device=x.device)
+    y2 = torch.empty(B, Ho, Wo, Cout - split, dtype=torch.bfloat16, device=x.device)
+    if _recorder is not None:
+        _recorder.add(3, (x, w_s2d, scale, shift, y, y2), x=x, w=w_s2d, scale=scale, shift=shift, y=y, y2=y2, B=B, H=H,
+                      W=W, Cx=Cx, Cout=Cout, KH=3, KW=3, stride=2, pad=1, relu=1 if relu else 0, dt=DT_BF16,
+                      split=split)
+    with _timed(tag):
+        N.check(N.lib().lss_conv2d_s2_dual_fwd(N.ptr(x), N.ptr(w_s2d), N.ptr(scale), N.ptr(shift), N.ptr(y), N.ptr(y2),
+                                               B, H, W, Cx, Cout, split, 3, 1, 1 if relu else 0, N.stream()),
+                "lss_conv2d_s2_dual_fwd")
+    return y, y2
+
+
 def conv3x3_head_nchw(x, w_packed, scale, shift, head_w, head_b, x2=None, up=1, relu=True, tag="conv2d_fwd"):
     """3x3/s1/p1 conv (+fused upsample/concat) + scale/shift + ReLU + 1x1 head in one launch.
     x (B,H,W,Cx) bf16 NHWC; head_w (n,128) fp32; returns (B, n, H*up, W*up) fp32 NCHW."""

@@ -561,3 +561,26 @@ def test_splat_ragged_voxel_populations(ops):
             if n <= 64:
                 ix, iy = (5 * k + 3 * b) % 32, (7 * k + 11 * b) % 32
                 assert torch.equal(bev[b, :, ix, iy], bev2[b, :, ix, iy])
+
+
+@pytest.mark.parametrize("shape", [(2, 100, 100, 64, 128), (1, 50, 50, 128, 256), (2, 37, 41, 64, 128)])
+def test_k8_dual_output_stride2_conv(ops, shape):
+    """conv1 (3x3/2) + 1x1/2 downsample of a BasicBlock in one launch == the two separate launches."""
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, H, W, Cin, generator=g).bfloat16().cuda()
+    w1 = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).cuda()
+    wd = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).cuda()
+    sc = (torch.rand(2 * Cout, generator=g) + 0.5).cuda()
+    sh = torch.randn(2 * Cout, generator=g).cuda()
+    frame = torch.zeros(Cout, Cin, 3, 3, device="cuda")
+    frame[:, :, 1, 1] = wd[:, :, 0, 0]
+    wcat = torch.cat([ops.pack_conv_weight_s2d(w1, 1), ops.pack_conv_weight_s2d(frame, 1)], 1).contiguous()
+    y, y2 = ops.conv2d_s2_dual_nhwc(x, wcat, sc, sh, Cout, relu=True)
+    ref1 = ops.conv2d_s2_nhwc(x, ops.pack_conv_weight_s2d(w1, 1), 3, 1, sc[:Cout].contiguous(), sh[:Cout].contiguous(), None, True)
+    ref2 = ops.conv2d_s2_nhwc(x, ops.pack_conv_weight(wd, ops.DT_BF16), 1, 0, sc[Cout:].contiguous(), sh[Cout:].contiguous(),
+                              None, False)
+    assert y.shape == ref1.shape and y2.shape == ref2.shape
+    assert torch.equal(y, ref1)
+    assert float((y2.float() - ref2.float()).abs().max()) <= 2e-2 * float(ref2.float().abs().max())
+    assert float(y2.min()) < 0  # no activation on the second output
