@@ -165,6 +165,15 @@ int lss_depth_fuse_softmax_fwd(const float* d3, const float* d4, const float* w_
                                const float* scale, const float* shift, int BN, int D, int H, int W,
                                int H4, int W4, float* depth, void* stream);
 
+/* K3 (voxel ids + histogram, no geom output) and K2 (f32-MFMA depthnet + softmax) in ONE launch: the
+ * two are independent and neither fills the chip, so their workgroups share it.  Same arguments and
+ * results as lss_points_to_voxels + lss_depthnet_softmax_fwd(math = LSS_DT_F32). */
+int lss_depthnet_voxels_fwd(const float* frustum, const float* inv_post_rots, const float* post_trans,
+                            const float* combine, const float* trans, const float* dx, const float* bx,
+                            const float* x, const float* w, const float* bias, int B, int N, int D, int fH,
+                            int fW, int Cin, int C, int X, int Y, int Z, int32_t* voxel,
+                            int32_t* vox_count, float* depth, float* feat, void* stream);
+
 /* ---------------------------------------------------------------------------
  * K5/K6  fused lift + splat: bev[v, c] = sum_{p in voxel v} w[p] * feat[row(p), c]
  *        (w = the depth weight K4 stored next to the point id)

@@ -9,130 +9,18 @@
 //   depth (BN, D, HW)   - same as the reference's `depth` tensor
 //   feat  (BN*HW, C)    - channels-last, one 256-B row per pixel at C = 64
 // The (B*N, C, D, fH, fW) lifted tensor of ref :84 is never written.
-#include "lss_common.h"
+#include "depthnet_body.h"
 
 namespace {
 
-constexpr int PIX = 16;         // pixels per workgroup
-constexpr int LDS_LD = PIX + 1; // padded row of the [n][pix] logits tile
+using namespace lss_depthnet;
 
-// Shared tail of both kernels: K-quarter partials -> LDS -> bias -> outputs.
-template <int NT>
-__device__ __forceinline__ void depthnet_epilogue(const f32x4 (&acc)[NT], float* lds,
-                                                  const float* __restrict__ bias_d,
-                                                  const float* __restrict__ bias_c, int feat_row0,
-                                                  bool softmax, int bn, int pix0, int HW, int D,
-                                                  int C, float* __restrict__ depth,
-                                                  float* __restrict__ feat) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = lane & 15, j = lane >> 4;
-  // logit rows: depth bins at [0, D), context channels at [feat_row0, feat_row0 + C)
-  const int NO = feat_row0 + C;
-  // partial[wave][n][pix] -> LDS
-  float* part = lds;  // [4][NT*16][LDS_LD]
-  const int NR = NT * 16;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      part[((size_t)wave * NR + 16 * t + 4 * j + r) * LDS_LD + col] = acc[t][r];
-  __syncthreads();
-  // reduce the four K quarters (fixed order -> deterministic), add bias
-  float* logit = lds + 4 * NR * LDS_LD;  // [NR][LDS_LD]
-  for (int e = tid; e < NO * PIX; e += 256) {
-    const int n = e / PIX, p = e % PIX;
-    const int o = n * LDS_LD + p;
-    float v = part[o] + part[NR * LDS_LD + o];
-    v += part[2 * NR * LDS_LD + o];
-    v += part[3 * NR * LDS_LD + o];
-    if (n < D) v += bias_d[n];
-    else if (n >= feat_row0) v += bias_c[n - feat_row0];
-    logit[o] = v;
-  }
-  __syncthreads();
-
-  // context features: feat[(bn*HW + pix)*C + c] = logit[D + c][pix]
-  for (int e = tid; e < PIX * C; e += 256) {
-    const int p = e / C, c = e % C;
-    if (pix0 + p < HW) feat[((size_t)bn * HW + pix0 + p) * C + c] = logit[(feat_row0 + c) * LDS_LD + p];
-  }
-  if (!softmax) {  // raw logits (a later kernel fuses them, ref MultiScaleDepthNet)
-    for (int e = tid; e < D * PIX; e += 256) {
-      const int d = e / PIX, p = e % PIX;
-      if (pix0 + p < HW) depth[((size_t)bn * D + d) * HW + pix0 + p] = logit[d * LDS_LD + p];
-    }
-    return;
-  }
-  // softmax over d for each of the 16 pixels: 16 lanes per pixel
-  {
-    const int p = tid & 15, part_id = tid >> 4;  // 16 parts
-    float m = -INFINITY;
-    for (int d = part_id; d < D; d += 16) m = fmaxf(m, logit[d * LDS_LD + p]);
-    // combine the 16 parts of a pixel: lanes p, p+16, p+32, p+48 of 4 waves -> LDS
-    float* red = part;  // reuse: [16 parts][16 pix]
-    red[part_id * PIX + p] = m;
-    __syncthreads();
-    float mx = red[p];
-#pragma unroll
-    for (int q = 1; q < 16; ++q) mx = fmaxf(mx, red[q * PIX + p]);
-    __syncthreads();
-    float s = 0.f;
-    for (int d = part_id; d < D; d += 16) {
-      const float e = expf(logit[d * LDS_LD + p] - mx);
-      logit[d * LDS_LD + p] = e;
-      s += e;
-    }
-    red[part_id * PIX + p] = s;
-    __syncthreads();
-    float sum = red[p];
-#pragma unroll
-    for (int q = 1; q < 16; ++q) sum += red[q * PIX + p];
-    if (pix0 + p < HW)
-      for (int d = part_id; d < D; d += 16)
-        depth[((size_t)bn * D + d) * HW + pix0 + p] = logit[d * LDS_LD + p] / sum;
-  }
-}
-
-// MFMA operand maps (cdna_hip_programming.md section 3):
-//   16x16x4 f32:  A[row = l&15][k = l>>4],  B[k = l>>4][col = l&15],
-//                 D[row = 4*(l>>4) + r][col = l&15], r = 0..3
-// Within a 16-deep K block the four k-steps s = 0..3 use k = kb + 4*(l>>4) + s,
-// so one 16-B load of W[n][kb + 4*(l>>4) ..+3] feeds four MFMAs.
 template <int NT>
 __global__ __launch_bounds__(256) void depthnet_softmax_f32_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     int Cin, int HW, int D, int C, float* __restrict__ depth, float* __restrict__ feat) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = lane & 15, j = lane >> 4;
-  const int bn = blockIdx.y;
-  const int pix0 = blockIdx.x * PIX;
-  const int NO = D + C;
-  const int pix = min(pix0 + col, HW - 1);
-  const int kq = Cin >> 2;  // K quarter of this wave
-  const float* xb = x + ((size_t)bn * Cin + (size_t)wave * kq) * HW + pix;
-  const float* wb = w + (size_t)wave * kq + 4 * j;
-
-  f32x4 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  for (int kb = 0; kb < kq; kb += 16) {
-    float xs[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) xs[s] = xb[(size_t)(kb + 4 * j + s) * HW];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int n = 16 * t + col;
-      f32x4 wa = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (n < NO) wa = *reinterpret_cast<const f32x4*>(wb + (size_t)n * Cin + kb);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], xs[s], acc[t], 0, 0, 0);
-    }
-  }
-
-  depthnet_epilogue<NT>(acc, lds, bias, bias + D, D, true, bn, pix0, HW, D, C, depth, feat);
+  depthnet_softmax_f32_body<NT>(x, w, bias, Cin, HW, D, C, depth, feat, blockIdx.x, blockIdx.y, lds);
 }
 
 // bf16 variant: x and W are rounded to bf16 in registers (inputs stay fp32 in

@@ -5,7 +5,7 @@
 // every 3x3 * 3 product of get_geometry (ref: src/model_BEV_TXT.py:60,67) as
 // ((m0*p0 + m1*p1) + m2*p2) with each mul/add rounded to fp32.
 // tests/test_build.py greps the ISA of points_to_voxels_kernel for v_fma/v_mac.
-#include "lss_common.h"
+#include "depthnet_body.h"
 
 namespace {
 
@@ -48,15 +48,15 @@ __device__ __forceinline__ int quantise_point(float g0, float g1, float g2,
   return ((b * X + ix) * Y + iy) * Z + iz;
 }
 
-// grid = (ceil(D*fH*fW / 256), B*N); one thread per frustum point of one camera
-__global__ __launch_bounds__(256) void points_to_voxels_kernel(
+// one thread per frustum point of camera image bn; tile_x = 256-point block within the image
+__device__ __forceinline__ void points_to_voxels_body(
     const float* __restrict__ frustum, const float* __restrict__ inv_post_rots,
     const float* __restrict__ post_trans, const float* __restrict__ combine,
     const float* __restrict__ trans, const float* __restrict__ dx,
     const float* __restrict__ bx, int Ncam, int DHW, int X, int Y, int Z,
-    int32_t* __restrict__ voxel, int32_t* __restrict__ vox_count, float* __restrict__ geom) {
-  const int bn = blockIdx.y;
-  const int f = blockIdx.x * 256 + threadIdx.x;
+    int32_t* __restrict__ voxel, int32_t* __restrict__ vox_count, float* __restrict__ geom, int tile_x,
+    int bn) {
+  const int f = tile_x * 256 + threadIdx.x;
   if (f >= DHW) return;
   Mat3 ipr, cmb;
   load_mat3(inv_post_rots + bn * 9, ipr);  // block-uniform -> scalar loads
@@ -87,6 +87,45 @@ __global__ __launch_bounds__(256) void points_to_voxels_kernel(
   const int v = quantise_point(g0, g1, g2, dx, bx, bn / Ncam, X, Y, Z);
   if (v >= 0 && vox_count) atomicAdd(vox_count + v, 1);
   voxel[(size_t)bn * DHW + f] = v;
+}
+
+// grid = (ceil(D*fH*fW / 256), B*N)
+__global__ __launch_bounds__(256) void points_to_voxels_kernel(
+    const float* __restrict__ frustum, const float* __restrict__ inv_post_rots,
+    const float* __restrict__ post_trans, const float* __restrict__ combine,
+    const float* __restrict__ trans, const float* __restrict__ dx,
+    const float* __restrict__ bx, int Ncam, int DHW, int X, int Y, int Z,
+    int32_t* __restrict__ voxel, int32_t* __restrict__ vox_count, float* __restrict__ geom) {
+  points_to_voxels_body(frustum, inv_post_rots, post_trans, combine, trans, dx, bx, Ncam, DHW, X, Y, Z, voxel,
+                        vox_count, geom, blockIdx.x, blockIdx.y);
+}
+
+// K2 || K3 in ONE launch: the two kernels are independent (K2 reads the trunk features, K3 the
+// calibration), both are latency-bound and neither fills the chip, so their workgroups share
+// it: blocks [0, n2) run the depthnet body (they are the longer ones and start first), the rest
+// the geometry body.  One kernel boundary less per step and K3 hides under K2.
+struct FusedK2K3Args {
+  // K2
+  const float* x; const float* w; const float* bias; int Cin, HW, D, C; float* depth; float* feat;
+  int gx2, n2;  // pixel tiles per image, number of K2 blocks
+  // K3
+  const float* frustum; const float* inv_post_rots; const float* post_trans; const float* combine;
+  const float* trans; const float* dx; const float* bx; int Ncam, DHW, X, Y, Z;
+  int32_t* voxel; int32_t* vox_count; int gx3;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void depthnet_and_voxels_kernel(FusedK2K3Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int id = blockIdx.x;
+  if (id < a.n2) {
+    lss_depthnet::depthnet_softmax_f32_body<NT>(a.x, a.w, a.bias, a.Cin, a.HW, a.D, a.C, a.depth, a.feat, id % a.gx2,
+                                                id / a.gx2, lds);
+  } else {
+    const int k = id - a.n2;
+    points_to_voxels_body(a.frustum, a.inv_post_rots, a.post_trans, a.combine, a.trans, a.dx, a.bx, a.Ncam, a.DHW,
+                          a.X, a.Y, a.Z, a.voxel, a.vox_count, nullptr, k % a.gx3, k / a.gx3);
+  }
 }
 
 __global__ __launch_bounds__(256) void geom_to_voxels_kernel(const float* __restrict__ geom,
@@ -262,4 +301,47 @@ extern "C" const char* lss_error_string(int code) {
   }
   if (code > 0) return hipGetErrorString((hipError_t)code);
   return "lss: unknown error";
+}
+
+// K3 (voxel ids + histogram) and K2 (depthnet + softmax, f32 MFMA) as one launch; arguments as
+// lss_points_to_voxels (without geom) and lss_depthnet_softmax_fwd (math = LSS_DT_F32).
+extern "C" int lss_depthnet_voxels_fwd(const float* frustum, const float* inv_post_rots, const float* post_trans,
+                                       const float* combine, const float* trans, const float* dx, const float* bx,
+                                       const float* x, const float* w, const float* bias, int B, int N, int D, int fH,
+                                       int fW, int Cin, int C, int X, int Y, int Z, int32_t* voxel,
+                                       int32_t* vox_count, float* depth, float* feat, void* stream) {
+  LSS_CHECK_PTR(frustum); LSS_CHECK_PTR(inv_post_rots); LSS_CHECK_PTR(post_trans); LSS_CHECK_PTR(combine);
+  LSS_CHECK_PTR(trans); LSS_CHECK_PTR(dx); LSS_CHECK_PTR(bx); LSS_CHECK_PTR(voxel); LSS_CHECK_PTR(x);
+  LSS_CHECK_PTR(w); LSS_CHECK_PTR(bias); LSS_CHECK_PTR(depth); LSS_CHECK_PTR(feat);
+  LSS_CHECK_POS(B); LSS_CHECK_POS(N); LSS_CHECK_POS(D); LSS_CHECK_POS(fH); LSS_CHECK_POS(fW);
+  LSS_CHECK_POS(X); LSS_CHECK_POS(Y); LSS_CHECK_POS(Z); LSS_CHECK_POS(Cin); LSS_CHECK_POS(C);
+  const long long DHW = (long long)D * fH * fW, P = DHW * B * N, nvox = (long long)B * X * Y * Z;
+  if (P >= (1LL << 31) || nvox >= (1LL << 31) || B * N > 65535 || Cin % 64 != 0 || X >= (1 << 24) ||
+      Y >= (1 << 24) || Z >= (1 << 24))
+    return LSS_E_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(w) & 15) != 0) return LSS_E_ALIGN;
+  FusedK2K3Args a;
+  a.x = x; a.w = w; a.bias = bias; a.Cin = Cin; a.HW = fH * fW; a.D = D; a.C = C; a.depth = depth; a.feat = feat;
+  a.gx2 = lss_cdiv(a.HW, lss_depthnet::PIX);
+  a.n2 = a.gx2 * B * N;
+  a.frustum = frustum; a.inv_post_rots = inv_post_rots; a.post_trans = post_trans; a.combine = combine;
+  a.trans = trans; a.dx = dx; a.bx = bx; a.Ncam = N; a.DHW = (int)DHW; a.X = X; a.Y = Y; a.Z = Z;
+  a.voxel = voxel; a.vox_count = vox_count;
+  a.gx3 = lss_cdiv(DHW, 256);
+  const long long nblk = (long long)a.n2 + (long long)a.gx3 * B * N;
+  if (nblk >= (1LL << 31)) return LSS_E_SHAPE;
+  const int NT = (D + C + 15) / 16;
+  const size_t lds_bytes = (size_t)5 * NT * 16 * lss_depthnet::LDS_LD * sizeof(float);
+  hipStream_t st = lss_stream(stream);
+#define LSS_F_CASE(n)                                                                                       \
+  case n:                                                                                                   \
+    hipLaunchKernelGGL(depthnet_and_voxels_kernel<n>, dim3((unsigned)nblk), dim3(256), lds_bytes, st, a); \
+    break;
+  switch (NT) {
+    LSS_F_CASE(1) LSS_F_CASE(2) LSS_F_CASE(3) LSS_F_CASE(4) LSS_F_CASE(5) LSS_F_CASE(6) LSS_F_CASE(7) LSS_F_CASE(8)
+    LSS_F_CASE(9) LSS_F_CASE(10) LSS_F_CASE(11) LSS_F_CASE(12)
+    default: return LSS_E_SHAPE;
+  }
+#undef LSS_F_CASE
+  return lss_launch_status();
 }

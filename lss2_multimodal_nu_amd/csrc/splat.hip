@@ -19,6 +19,8 @@
 //
 // The lifted (B,N,D,fH,fW,C) tensor of the reference (src/modules.py:84,
 // src/model_BEV_TXT.py:80,89) exists only as `w * feat` in registers.
+#include <stdlib.h>
+
 #include "lss_common.h"
 
 namespace {
@@ -402,11 +404,19 @@ extern "C" int lss_lift_splat_forward(const float* frustum, const float* inv_pos
                                       int C, int X, int Y, int Z, int32_t* voxel, int32_t* vox_count,
                                       int32_t* vox_list, int32_t* entries, int32_t* cursor, float* depth,
                                       float* feat, void* bev, int layout, int math, void* stream) {
-  int rc = lss_points_to_voxels(frustum, inv_post_rots, post_trans, combine, trans, dx, bx, B, N, D, fH,
-                                fW, X, Y, Z, voxel, vox_count, nullptr, stream);
-  if (rc) return rc;
-  rc = lss_depthnet_softmax_fwd(x, w, bias, B * N, Cin, fH * fW, D, C, depth, feat, math, stream);
-  if (rc) return rc;
+  int rc;
+  if (math == LSS_DT_F32 && getenv("LSS_NO_K2K3") == nullptr) {
+    // K2 || K3 as one launch (independent, both latency-bound)
+    rc = lss_depthnet_voxels_fwd(frustum, inv_post_rots, post_trans, combine, trans, dx, bx, x, w, bias, B, N, D, fH,
+                                 fW, Cin, C, X, Y, Z, voxel, vox_count, depth, feat, stream);
+    if (rc) return rc;
+  } else {
+    rc = lss_points_to_voxels(frustum, inv_post_rots, post_trans, combine, trans, dx, bx, B, N, D, fH, fW, X, Y, Z,
+                              voxel, vox_count, nullptr, stream);
+    if (rc) return rc;
+    rc = lss_depthnet_softmax_fwd(x, w, bias, B * N, Cin, fH * fW, D, C, depth, feat, math, stream);
+    if (rc) return rc;
+  }
   rc = lss_bucket_points(voxel, depth, B * N * D * fH * fW, D, fH * fW, B * X * Y * Z, vox_count, vox_list,
                          entries, cursor, stream);
   if (rc) return rc;
