@@ -1123,8 +1123,15 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
   const int tilesX = lss_cdiv(a.Wo, 16), tilesY = lss_cdiv(a.Ho, 8);
   dim3 g(tilesX * tilesY * B, 1);
   hipStream_t st = lss_stream(stream);
-  if (fused) hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
-  else hipLaunchKernelGGL((conv_lds_kernel<2, 128, 0, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
+  // the fused-gather form takes the 32-channel steps (three workgroups per CU), as in launch_conv_lds
+  bool kc32 = fused && a.Cx % 32 == 0 && a.C2 % 32 == 0;
+  if (const char* e = getenv("LSS_CONV_KC")) kc32 = kc32 && atoi(e) == 32;
+  if (fused && kc32)
+    hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1, 32>), g, dim3(256), 0, st, a, tilesX, tilesY);
+  else if (fused)
+    hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
+  else
+    hipLaunchKernelGGL((conv_lds_kernel<2, 128, 0, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
   return lss_launch_status();
 }
 
