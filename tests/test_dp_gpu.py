@@ -1,0 +1,80 @@
+"""N > 1 training path on the GPU: two ranks share the one GPU of the box (gloo carries the bucket
+all-reduce), each runs the LSS training step on its shard of the batch - native lift-splat backward
+and the native conv+BatchNorm units under bf16 autocast - and both must hold identical parameters
+after every step (the DP contract of dp.train_step), with a finite, decreasing loss."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GRID = dict(xbound=[-50.0, 50.0, 0.5], ybound=[-50.0, 50.0, 0.5], zbound=[-10.0, 10.0, 20.0],
+            dbound=[4.0, 45.0, 1.0])
+AUG = {"final_dim": (128, 352), "Ncams": 6}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    import lss2_multimodal_nu_amd as L
+    from lss2_multimodal_nu_amd import dp, ops
+    from lss2_multimodal_nu_amd.tools import weighted_cross_entropy
+    from oracle import lss_oracle as lo
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    m = L.compile_model_lss(1, GRID, AUG, 4).cuda().train()  # one sample per rank
+    bucket = dp.GradBucket(m.parameters())
+    opt = torch.optim.Adam(bucket.params, lr=1e-3)
+    g = torch.Generator().manual_seed(100 + rank)  # different data per rank
+    x = torch.randn(6, 512, 8, 22, generator=g).cuda()
+    tgt = torch.randint(0, 4, (1, 200, 200), generator=g).cuda()
+    w = torch.tensor([1.0, 10.0, 5.0, 10.0]).cuda()
+    calib = lo.synthetic_rig(1, 6, train_aug=True, seed=rank)
+
+    class Amp(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, *a):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return self.inner(*a)
+
+    wrapped = Amp(m)
+    spans = ops.KernelTimer(fine=True)
+    ops.set_timer(spans)
+    losses = []
+    for _ in range(4):
+        losses.append(float(dp.train_step(wrapped, bucket, opt, lambda y: weighted_cross_entropy(y.float(), tgt, w),
+                                          (x,) + tuple(calib))))
+    ops.set_timer(None)
+    flat = torch.cat([p.detach().reshape(-1) for p in bucket.params]).cpu()
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        torch.save({"equal": all(torch.equal(gathered[0], t) for t in gathered), "losses": losses,
+                    "tags": sorted(spans.spans), "finite": bool(torch.isfinite(flat).all())}, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gpu_training_keeps_ranks_identical(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "dp_gpu.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["equal"] and got["finite"]
+    assert {"conv_bn_act_train_fwd", "conv_bn_act_train_bwd", "weighted_ce_fwd"} <= set(got["tags"])
+    assert got["losses"][-1] < got["losses"][0]
