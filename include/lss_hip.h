@@ -323,6 +323,23 @@ int lss_bn_train_bwd(const void* dy, const void* y, const void* z, long long M, 
                      const float* gamma, const float* save_mean, const float* save_invstd, int relu,
                      void* workspace, void* dz, void* dres, float* dgamma, float* dbeta, void* stream);
 
+/* Split forms for SYNCHRONISED BatchNorm under data parallelism: the per-channel sums
+ * come back as a (2, C) fp32 vector, the caller all-reduces it over the ranks, and the second half
+ * normalises this rank's rows with the GLOBAL statistics (M_total = rows of all ranks).
+ *   lss_bn_partial_sums  mode 0: (sum z, sum z^2);  mode 1: (sum g, sum g*xhat), g = dy masked by ReLU
+ *   lss_bn_train_fwd_from_sums / _bwd_from_sums: as lss_bn_train_fwd / _bwd with the statistics given.
+ *   (_bwd_from_sums writes the GLOBAL sums to dgamma / dbeta; a DP caller keeps its local sums instead.) */
+int lss_bn_partial_sums(const void* z, const void* dy, const void* y, const float* mean, const float* invstd,
+                        long long M, int C, int relu, int mode, void* workspace, float* sums, void* stream);
+int lss_bn_train_fwd_from_sums(const void* z, const void* residual, long long M, int C, const float* sums,
+                               long long M_total, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float momentum, float eps, int relu, void* workspace,
+                               void* y, float* save_mean, float* save_invstd, void* stream);
+int lss_bn_train_bwd_from_sums(const void* dy, const void* y, const void* z, long long M, int C,
+                               const float* sums, long long M_total, const float* gamma,
+                               const float* save_mean, const float* save_invstd, int relu, void* workspace,
+                               void* dz, void* dres, float* dgamma, float* dbeta, void* stream);
+
 /* One-call training units (the training step is framework-bound: chaining the launches here costs
  * two host calls per conv+BN unit instead of sixteen).
  * forward:  z = conv3x3(x) with x = x1 (up = 1, C2 = 0) or cat([x2, bilinear_align_corners(x1, up)]),

@@ -48,6 +48,11 @@ SIGNATURES = {
     "lss_bn_train_fwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _i,
                               _vp, _vp, _vp, _vp, _vp]),
     "lss_bn_train_bwd": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lss_bn_partial_sums": (_i, [_vp] * 5 + [ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp]),
+    "lss_bn_train_fwd_from_sums": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp,
+                                        ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp]),
+    "lss_bn_train_bwd_from_sums": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp, _i,
+                                        _vp, _vp, _vp, _vp, _vp, _vp]),
     "lss_conv_bn_act_train_fwd": (_i, [_vp] * 14 + [_i] * 7 + [ctypes.c_float, ctypes.c_float, _i, _vp]),
     "lss_conv_bn_act_train_bwd": (_i, [_vp] * 11 + [_sz] + [_vp] * 9 + [_i] * 8 + [_vp]),
     "lss_weighted_ce_fwd": (_i, [_vp, _vp, _vp, _i, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp]),

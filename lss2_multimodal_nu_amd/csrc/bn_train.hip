@@ -335,3 +335,90 @@ extern "C" int lss_conv_bn_act_train_bwd(const void* dy, const void* y, const vo
   }
   return rc;
 }
+
+// ---------------------------------------------------------------------------
+// Split forms for synchronised BatchNorm under data parallelism: the per-channel sums leave the
+// device function as a (2, C) vector, the caller all-reduces them over the ranks (RCCL), and the
+// second half normalises with the GLOBAL statistics - so W ranks x B/W samples compute exactly the
+// batch statistics of one device holding B samples.
+namespace {
+
+// sums[which][c] = fixed-order sum of the per-workgroup partials
+__global__ void bn_collapse_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ sums) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  float s1, s2;
+  sum_partials(part, nblk, C, c, s1, s2);
+  if ((threadIdx.x & 63) == 0) {
+    sums[c] = s1;
+    sums[C + c] = s2;
+  }
+}
+
+}  // namespace
+
+// mode 0: sums = (sum z, sum z^2);  mode 1: sums = (sum g, sum g * xhat) with g = dy * [y > 0] (relu) or dy
+extern "C" int lss_bn_partial_sums(const void* z, const void* dy, const void* y, const float* mean,
+                                   const float* invstd, long long M, int C, int relu, int mode, void* workspace,
+                                   float* sums, void* stream) {
+  LSS_CHECK_PTR(z); LSS_CHECK_PTR(workspace); LSS_CHECK_PTR(sums);
+  if (!bn_shape_ok(M, C) || (mode != 0 && mode != 1)) return LSS_E_SHAPE;
+  if (mode == 1 && (dy == nullptr || mean == nullptr || invstd == nullptr || (relu && y == nullptr))) return LSS_E_NULL;
+  hipStream_t st = lss_stream(stream);
+  const int nblk = red_blocks(M);
+  float* part = static_cast<float*>(workspace);
+  const unsigned short* zz = static_cast<const unsigned short*>(z);
+  if (mode == 0)
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(nblk), dim3(256), 0, st, zz, nullptr, nullptr, nullptr, nullptr, M,
+                       C, 0, part);
+  else
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(nblk), dim3(256), 0, st, zz, static_cast<const unsigned short*>(dy),
+                       static_cast<const unsigned short*>(y), mean, invstd, M, C, relu, part);
+  hipLaunchKernelGGL(bn_collapse_kernel, dim3(lss_cdiv(C, 4)), dim3(256), 0, st, part, nblk, C, sums);
+  return lss_launch_status();
+}
+
+// forward, second half: statistics from `sums` over M_total rows (all ranks), applied to this rank's M rows
+extern "C" int lss_bn_train_fwd_from_sums(const void* z, const void* residual, long long M, int C,
+                                          const float* sums, long long M_total, const float* gamma,
+                                          const float* beta, float* running_mean, float* running_var,
+                                          float momentum, float eps, int relu, void* workspace, void* y,
+                                          float* save_mean, float* save_invstd, void* stream) {
+  LSS_CHECK_PTR(z); LSS_CHECK_PTR(sums); LSS_CHECK_PTR(gamma); LSS_CHECK_PTR(beta); LSS_CHECK_PTR(workspace);
+  LSS_CHECK_PTR(y); LSS_CHECK_PTR(save_mean); LSS_CHECK_PTR(save_invstd);
+  if (!bn_shape_ok(M, C) || M_total < M) return LSS_E_SHAPE;
+  hipStream_t st = lss_stream(stream);
+  float* scale = static_cast<float*>(workspace) + (size_t)red_blocks(M) * 2 * C;
+  float* shift = scale + C;
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(lss_cdiv(C, 4)), dim3(256), 0, st, sums, 1, M_total, C, gamma, beta,
+                     eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
+  const long long n8 = M * (C / 8);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n8)), dim3(256), 0, st, static_cast<const unsigned short*>(z),
+                     static_cast<const unsigned short*>(residual), scale, shift, n8, C, relu,
+                     static_cast<unsigned short*>(y));
+  return lss_launch_status();
+}
+
+// backward, second half: `sums` = all-reduced (sum g, sum g xhat) over M_total rows.  dgamma / dbeta
+// written here are those GLOBAL sums; a data-parallel caller keeps its LOCAL sums as the parameter
+// gradients (the gradient all-reduce averages them) and uses this call for dz only.
+extern "C" int lss_bn_train_bwd_from_sums(const void* dy, const void* y, const void* z, long long M, int C,
+                                          const float* sums, long long M_total, const float* gamma,
+                                          const float* save_mean, const float* save_invstd, int relu,
+                                          void* workspace, void* dz, void* dres, float* dgamma, float* dbeta,
+                                          void* stream) {
+  LSS_CHECK_PTR(dy); LSS_CHECK_PTR(z); LSS_CHECK_PTR(sums); LSS_CHECK_PTR(gamma); LSS_CHECK_PTR(save_mean);
+  LSS_CHECK_PTR(save_invstd); LSS_CHECK_PTR(workspace); LSS_CHECK_PTR(dz); LSS_CHECK_PTR(dgamma); LSS_CHECK_PTR(dbeta);
+  if (relu && y == nullptr) return LSS_E_NULL;
+  if (!bn_shape_ok(M, C) || M_total < M) return LSS_E_SHAPE;
+  hipStream_t st = lss_stream(stream);
+  float* coef = static_cast<float*>(workspace) + (size_t)red_blocks(M) * 2 * C;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(lss_cdiv(C, 4)), dim3(256), 0, st, sums, 1, M_total, C, gamma,
+                     save_invstd, dgamma, dbeta, coef);
+  const long long n8 = M * (C / 8);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n8)), dim3(256), 0, st, static_cast<const unsigned short*>(z),
+                     static_cast<const unsigned short*>(dy), static_cast<const unsigned short*>(y), save_mean,
+                     save_invstd, coef, n8, C, relu, static_cast<unsigned short*>(dz),
+                     static_cast<unsigned short*>(dres));
+  return lss_launch_status();
+}

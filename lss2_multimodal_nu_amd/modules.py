@@ -196,6 +196,63 @@ class _ConvBNActFn(torch.autograd.Function):
                 out(dres, dtr), None, None, None, None, None, None)
 
 
+class _SyncBNActFn(torch.autograd.Function):
+    """BatchNorm(train) + residual + ReLU with statistics over ALL data-parallel ranks: local
+    per-channel sums on the HIP kernels, ONE small all-reduce (2*C floats) per direction over the
+    process group, then the normalisation with the global statistics.  Parameter gradients are the
+    local sums (the gradient all-reduce of the DP step averages them, like torch's SyncBatchNorm)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, group):
+        import torch.distributed as dist
+        zn = _nhwc_bf16(z)
+        rn = None if residual is None else _nhwc_bf16(residual)
+        g32 = gamma.detach()
+        sums = ops.bn_partial_sums(zn, 0)
+        world = dist.get_world_size(group)
+        dist.all_reduce(sums, group=group)
+        m_total = (zn.numel() // zn.shape[-1]) * world  # equal shards (drop_last loaders, ref src/data.py:294)
+        y, mean, invstd = ops.bn_train_fwd_from_sums(zn, sums, m_total, g32, beta.detach(), running_mean, running_var,
+                                                     momentum, eps, relu, rn)
+        ctx.save_for_backward(zn, y, g32, mean, invstd)
+        ctx.cfg = (relu, residual is not None, group, m_total, z.dtype, None if residual is None else residual.dtype)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        import torch.distributed as dist
+        zn, y, g32, mean, invstd = ctx.saved_tensors
+        relu, has_res, group, m_total, dtz, dtr = ctx.cfg
+        gyn = _nhwc_bf16(gy)
+        local = ops.bn_partial_sums(zn, 1, dy=gyn, y=y, mean=mean, invstd=invstd, relu=relu)
+        glob = local.clone()
+        dist.all_reduce(glob, group=group)
+        want_res = has_res and ctx.needs_input_grad[3]
+        dz, dres = ops.bn_train_bwd_from_sums(gyn, y, zn, glob, m_total, g32, mean, invstd, relu, want_res)
+
+        def out(t, dt):
+            if t is None:
+                return None
+            t = t.permute(0, 3, 1, 2)
+            return t if t.dtype == dt else t.to(dt)
+
+        return (out(dz, dtz), local[1] if ctx.needs_input_grad[1] else None, local[0] if ctx.needs_input_grad[2] else None,
+                out(dres, dtr), None, None, None, None, None, None)
+
+
+def enable_sync_bn(module, group=None):
+    """Make every BatchNorm2d under `module` that runs on the HIP training units use statistics over
+    all ranks of `group` (default: the world group).  Call after torch.distributed is initialised;
+    `enable_sync_bn(module, False)` turns it off again."""
+    for m in module.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            if group is False:
+                m.__dict__.pop("_lss_sync", None)
+            else:
+                m.__dict__["_lss_sync"] = (group,)
+    return module
+
+
 def _bn_native_ok(bn, z_is_cuda):
     C = bn.num_features
     return (z_is_cuda and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
@@ -212,10 +269,11 @@ def _train_conv_bn_act(conv, bn, x1, relu, residual=None, up=None, x2=None):
             and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
             and conv.bias is None and conv.weight.dtype == torch.float32 and x1.shape[1] % 64 == 0 and c2 % 64 == 0
             and conv.out_channels % 8 == 0 and (scale == 1 or (x1.shape[2] > 1 and x1.shape[3] > 1))):
-        y = _ConvBNActFn.apply(x1, x2, conv.weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
-                               float(bn.momentum), float(bn.eps), bool(relu), scale)
-        bn.num_batches_tracked.add_(1)
-        return y
+        if "_lss_sync" not in bn.__dict__:
+            y = _ConvBNActFn.apply(x1, x2, conv.weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
+                                   float(bn.momentum), float(bn.eps), bool(relu), scale)
+            bn.num_batches_tracked.add_(1)
+            return y
     z = _train_conv(conv, x1) if up is None else _train_up_conv(conv, up, x1, x2)
     return _train_bn_act(bn, z, relu, residual)
 
@@ -224,8 +282,12 @@ def _train_bn_act(bn, z, relu, residual=None):
     """act(bn(z) (+ residual)) on the autograd path: one fused HIP forward/backward pair when the
     caller asked for bf16 math and the module is in training mode, the library ops otherwise."""
     if _native_training() and _bn_native_ok(bn, z.is_cuda):
-        y = _BNActFn.apply(z, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, float(bn.momentum),
-                           float(bn.eps), bool(relu))
+        if "_lss_sync" in bn.__dict__:
+            y = _SyncBNActFn.apply(z, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
+                                   float(bn.momentum), float(bn.eps), bool(relu), bn.__dict__["_lss_sync"][0])
+        else:
+            y = _BNActFn.apply(z, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, float(bn.momentum),
+                               float(bn.eps), bool(relu))
         bn.num_batches_tracked.add_(1)
         return y
     y = bn(z)

@@ -590,6 +590,45 @@ def bn_train_bwd(dy, y, z, gamma, mean, invstd, relu, want_dres):
     return dz, dres, dgamma, dbeta
 
 
+def bn_partial_sums(z, mode, dy=None, y=None, mean=None, invstd=None, relu=False):
+    """(2, C) fp32 per-channel sums of this rank's rows: mode 0 = (sum z, sum z^2); mode 1 = (sum g, sum g*xhat)."""
+    C = z.shape[-1]
+    M = z.numel() // C
+    sums = torch.empty(2, C, dtype=torch.float32, device=z.device)
+    N.check(N.lib().lss_bn_partial_sums(N.ptr(z), N.ptr(dy), N.ptr(y), N.ptr(mean), N.ptr(invstd), M, C,
+                                        1 if relu else 0, mode, N.ptr(_bn_workspace(M, C, z.device)), N.ptr(sums),
+                                        N.stream()), "lss_bn_partial_sums")
+    return sums
+
+
+def bn_train_fwd_from_sums(z, sums, m_total, gamma, beta, running_mean, running_var, momentum, eps, relu, residual=None):
+    C = z.shape[-1]
+    M = z.numel() // C
+    y = torch.empty_like(z)
+    mean = torch.empty(C, dtype=torch.float32, device=z.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=z.device)
+    N.check(N.lib().lss_bn_train_fwd_from_sums(N.ptr(z), N.ptr(residual), M, C, N.ptr(sums), int(m_total), N.ptr(gamma),
+                                               N.ptr(beta), N.ptr(running_mean), N.ptr(running_var), float(momentum),
+                                               float(eps), 1 if relu else 0, N.ptr(_bn_workspace(M, C, z.device)),
+                                               N.ptr(y), N.ptr(mean), N.ptr(invstd), N.stream()),
+            "lss_bn_train_fwd_from_sums")
+    return y, mean, invstd
+
+
+def bn_train_bwd_from_sums(dy, y, z, sums, m_total, gamma, mean, invstd, relu, want_dres):
+    C = z.shape[-1]
+    M = z.numel() // C
+    dz = torch.empty_like(z)
+    dres = torch.empty_like(z) if want_dres else None
+    scratch = torch.empty(2, C, dtype=torch.float32, device=z.device)  # the global dgamma / dbeta (unused by DP callers)
+    N.check(N.lib().lss_bn_train_bwd_from_sums(N.ptr(dy), N.ptr(y), N.ptr(z), M, C, N.ptr(sums), int(m_total),
+                                               N.ptr(gamma), N.ptr(mean), N.ptr(invstd), 1 if relu else 0,
+                                               N.ptr(_bn_workspace(M, C, z.device)), N.ptr(dz), N.ptr(dres),
+                                               scratch.data_ptr(), scratch.data_ptr() + 4 * C, N.stream()),
+            "lss_bn_train_bwd_from_sums")
+    return dz, dres
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 

@@ -78,3 +78,63 @@ def test_two_rank_gpu_training_keeps_ranks_identical(tmp_path):
     assert got["equal"] and got["finite"]
     assert {"conv_bn_act_train_fwd", "conv_bn_act_train_bwd", "weighted_ce_fwd"} <= set(got["tags"])
     assert got["losses"][-1] < got["losses"][0]
+
+
+def _sync_worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    import lss2_multimodal_nu_amd as L
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    be, x, tgt = _sync_problem()
+    L.enable_sync_bn(be)
+    lo_, hi_ = rank * 2, rank * 2 + 2
+    xs = x[lo_:hi_].clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = be(xs)
+    loss = ((y.float() - tgt[lo_:hi_]) ** 2).mean()
+    loss.backward()
+    grads = torch.cat([p.grad.detach().float().reshape(-1) for p in be.parameters()])
+    dist.all_reduce(grads)
+    grads /= world  # what dp.GradBucket.all_reduce_mean does
+    ys = [torch.empty_like(y.detach().float()) for _ in range(world)]
+    dist.all_gather(ys, y.detach().float().contiguous())
+    gxs = [torch.empty_like(xs.grad) for _ in range(world)]
+    dist.all_gather(gxs, xs.grad.contiguous())
+    rm = be.bn1.running_mean.detach().clone()
+    if rank == 0:
+        torch.save({"y": torch.cat(ys).cpu(), "grads": grads.cpu(), "gx": torch.cat(gxs).cpu() / world, "rm": rm.cpu()}, out)
+    dist.destroy_process_group()
+
+
+def _sync_problem():
+    import lss2_multimodal_nu_amd as L
+    torch.manual_seed(5)
+    be = L.BevEncode(64, 4).cuda().train()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(4, 64, 64, 48, generator=g).cuda()
+    x[2:] = x[2:] * 2.0 + 0.5  # the two shards have different statistics: unsynced BN would differ visibly
+    tgt = torch.randn(4, 4, 64, 48, generator=g).cuda()
+    return be, x, tgt
+
+
+@pytest.mark.timeout(600)
+def test_sync_bn_two_ranks_equal_one_device_whole_batch(tmp_path):
+    """with enable_sync_bn, 2 ranks x 2 samples reproduce one device x 4 samples."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "sync.pt")
+    mp.spawn(_sync_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    be, x, tgt = _sync_problem()
+    xr = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = be(xr)
+    ((y.float() - tgt) ** 2).mean().backward()
+    ref_g = torch.cat([p.grad.detach().float().reshape(-1) for p in be.parameters()]).cpu()
+    cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm() + 1e-30))  # noqa: E731
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))  # noqa: E731
+    assert rel(got["y"], y.detach().float().cpu()) < 2e-2
+    assert cos(got["grads"], ref_g) > 0.995 and rel(got["grads"], ref_g) < 0.1
+    assert cos(got["gx"], xr.grad.cpu()) > 0.99
+    assert rel(got["rm"], be.bn1.running_mean.detach().cpu()) < 1e-3  # global statistics in the running estimate
