@@ -435,6 +435,22 @@ int lss_lift_splat_forward(const float* frustum, const float* inv_post_rots, con
                            int32_t* vox_count, int32_t* vox_list, int32_t* entries, int32_t* cursor,
                            float* depth, float* feat, void* bev, int layout, int math, void* stream);
 
+/* Host-calibration forms: the four per-camera arrays arrive as ONE HOST buffer of B*N*24 floats,
+ * [inv_post_rots (B*N*9) | combine (B*N*9) | post_trans (B*N*3) | trans (B*N*3)], are read during the call
+ * and travel inside the kernel arguments (B*N <= 36): no H2D copy, no staging buffer, one launch boundary
+ * less.  Otherwise identical to lss_depthnet_voxels_fwd / lss_lift_splat_forward (f32 depthnet math). */
+int lss_depthnet_voxels_hostcal_fwd(const float* frustum, const float* calib_host, const float* dx,
+                                    const float* bx, const float* x, const float* w, const float* bias,
+                                    int B, int N, int D, int fH, int fW, int Cin, int C, int X, int Y,
+                                    int Z, int32_t* voxel, int32_t* vox_count, float* depth, float* feat,
+                                    void* stream);
+int lss_lift_splat_forward_hostcal(const float* frustum, const float* calib_host, const float* dx,
+                                   const float* bx, const float* x, const float* w, const float* bias,
+                                   int B, int N, int D, int fH, int fW, int Cin, int C, int X, int Y,
+                                   int Z, int32_t* voxel, int32_t* vox_count, int32_t* vox_list,
+                                   int32_t* entries, int32_t* cursor, float* depth, float* feat,
+                                   void* bev, int layout, void* stream);
+
 /* Layout / dtype conversion helpers between the reference's NCHW fp32 tensors
  * and the conv path's NHWC tensors. */
 int lss_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int dt,

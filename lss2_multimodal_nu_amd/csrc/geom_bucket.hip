@@ -48,21 +48,43 @@ __device__ __forceinline__ int quantise_point(float g0, float g1, float g2,
   return ((b * X + ix) * Y + iy) * Z + iz;
 }
 
+// the four per-camera calibration arrays, behind device pointers ...
+struct CalPtr {
+  const float* ipr; const float* pt; const float* cmb; const float* tr;
+  __device__ __forceinline__ float inv_post_rot(int bn, int i) const { return ipr[bn * 9 + i]; }
+  __device__ __forceinline__ float combine(int bn, int i) const { return cmb[bn * 9 + i]; }
+  __device__ __forceinline__ float post_tran(int bn, int i) const { return pt[bn * 3 + i]; }
+  __device__ __forceinline__ float tran(int bn, int i) const { return tr[bn * 3 + i]; }
+};
+// ... or carried INSIDE the kernel arguments (host calibration, <= CAL_MAX cameras): no H2D copy, no
+// staging buffer, one dependent launch boundary less.  Layout [inv_post_rots | combine | post_trans | trans].
+constexpr int CAL_MAX = 36;
+struct CalInline {
+  float v[CAL_MAX * 24];
+  int n;  // cameras
+  __device__ __forceinline__ float inv_post_rot(int bn, int i) const { return v[bn * 9 + i]; }
+  __device__ __forceinline__ float combine(int bn, int i) const { return v[n * 9 + bn * 9 + i]; }
+  __device__ __forceinline__ float post_tran(int bn, int i) const { return v[n * 18 + bn * 3 + i]; }
+  __device__ __forceinline__ float tran(int bn, int i) const { return v[n * 21 + bn * 3 + i]; }
+};
+
 // one thread per frustum point of camera image bn; tile_x = 256-point block within the image
+template <class Cal>
 __device__ __forceinline__ void points_to_voxels_body(
-    const float* __restrict__ frustum, const float* __restrict__ inv_post_rots,
-    const float* __restrict__ post_trans, const float* __restrict__ combine,
-    const float* __restrict__ trans, const float* __restrict__ dx,
+    const float* __restrict__ frustum, const Cal& cal, const float* __restrict__ dx,
     const float* __restrict__ bx, int Ncam, int DHW, int X, int Y, int Z,
     int32_t* __restrict__ voxel, int32_t* __restrict__ vox_count, float* __restrict__ geom, int tile_x,
     int bn) {
   const int f = tile_x * 256 + threadIdx.x;
   if (f >= DHW) return;
-  Mat3 ipr, cmb;
-  load_mat3(inv_post_rots + bn * 9, ipr);  // block-uniform -> scalar loads
-  load_mat3(combine + bn * 9, cmb);
-  const float pt0 = post_trans[bn * 3 + 0], pt1 = post_trans[bn * 3 + 1], pt2 = post_trans[bn * 3 + 2];
-  const float t0 = trans[bn * 3 + 0], t1 = trans[bn * 3 + 1], t2 = trans[bn * 3 + 2];
+  Mat3 ipr, cmb;  // block-uniform -> scalar loads
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    ipr.m[i] = cal.inv_post_rot(bn, i);
+    cmb.m[i] = cal.combine(bn, i);
+  }
+  const float pt0 = cal.post_tran(bn, 0), pt1 = cal.post_tran(bn, 1), pt2 = cal.post_tran(bn, 2);
+  const float t0 = cal.tran(bn, 0), t1 = cal.tran(bn, 1), t2 = cal.tran(bn, 2);
 
   // ref :59  points = frustum - post_trans
   const float p0 = __fsub_rn(frustum[f * 3 + 0], pt0);
@@ -96,8 +118,8 @@ __global__ __launch_bounds__(256) void points_to_voxels_kernel(
     const float* __restrict__ trans, const float* __restrict__ dx,
     const float* __restrict__ bx, int Ncam, int DHW, int X, int Y, int Z,
     int32_t* __restrict__ voxel, int32_t* __restrict__ vox_count, float* __restrict__ geom) {
-  points_to_voxels_body(frustum, inv_post_rots, post_trans, combine, trans, dx, bx, Ncam, DHW, X, Y, Z, voxel,
-                        vox_count, geom, blockIdx.x, blockIdx.y);
+  const CalPtr cal = {inv_post_rots, post_trans, combine, trans};
+  points_to_voxels_body(frustum, cal, dx, bx, Ncam, DHW, X, Y, Z, voxel, vox_count, geom, blockIdx.x, blockIdx.y);
 }
 
 // K2 || K3 in ONE launch: the two kernels are independent (K2 reads the trunk features, K3 the
@@ -123,8 +145,24 @@ __global__ __launch_bounds__(256) void depthnet_and_voxels_kernel(FusedK2K3Args 
                                                 id / a.gx2, lds);
   } else {
     const int k = id - a.n2;
-    points_to_voxels_body(a.frustum, a.inv_post_rots, a.post_trans, a.combine, a.trans, a.dx, a.bx, a.Ncam, a.DHW,
-                          a.X, a.Y, a.Z, a.voxel, a.vox_count, nullptr, k % a.gx3, k / a.gx3);
+    const CalPtr cal = {a.inv_post_rots, a.post_trans, a.combine, a.trans};
+    points_to_voxels_body(a.frustum, cal, a.dx, a.bx, a.Ncam, a.DHW, a.X, a.Y, a.Z, a.voxel, a.vox_count, nullptr,
+                          k % a.gx3, k / a.gx3);
+  }
+}
+
+// the same with the calibration inside the kernel arguments
+template <int NT>
+__global__ __launch_bounds__(256) void depthnet_and_voxels_hostcal_kernel(FusedK2K3Args a, CalInline cal) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int id = blockIdx.x;
+  if (id < a.n2) {
+    lss_depthnet::depthnet_softmax_f32_body<NT>(a.x, a.w, a.bias, a.Cin, a.HW, a.D, a.C, a.depth, a.feat, id % a.gx2,
+                                                id / a.gx2, lds);
+  } else {
+    const int k = id - a.n2;
+    points_to_voxels_body(a.frustum, cal, a.dx, a.bx, a.Ncam, a.DHW, a.X, a.Y, a.Z, a.voxel, a.vox_count, nullptr,
+                          k % a.gx3, k / a.gx3);
   }
 }
 
@@ -305,13 +343,18 @@ extern "C" const char* lss_error_string(int code) {
 
 // K3 (voxel ids + histogram) and K2 (depthnet + softmax, f32 MFMA) as one launch; arguments as
 // lss_points_to_voxels (without geom) and lss_depthnet_softmax_fwd (math = LSS_DT_F32).
-extern "C" int lss_depthnet_voxels_fwd(const float* frustum, const float* inv_post_rots, const float* post_trans,
-                                       const float* combine, const float* trans, const float* dx, const float* bx,
-                                       const float* x, const float* w, const float* bias, int B, int N, int D, int fH,
-                                       int fW, int Cin, int C, int X, int Y, int Z, int32_t* voxel,
-                                       int32_t* vox_count, float* depth, float* feat, void* stream) {
-  LSS_CHECK_PTR(frustum); LSS_CHECK_PTR(inv_post_rots); LSS_CHECK_PTR(post_trans); LSS_CHECK_PTR(combine);
-  LSS_CHECK_PTR(trans); LSS_CHECK_PTR(dx); LSS_CHECK_PTR(bx); LSS_CHECK_PTR(voxel); LSS_CHECK_PTR(x);
+static int depthnet_voxels_impl(const float* frustum, const float* inv_post_rots, const float* post_trans,
+                                const float* combine, const float* trans, const float* calib_host, const float* dx,
+                                const float* bx, const float* x, const float* w, const float* bias, int B, int N,
+                                int D, int fH, int fW, int Cin, int C, int X, int Y, int Z, int32_t* voxel,
+                                int32_t* vox_count, float* depth, float* feat, void* stream) {
+  LSS_CHECK_PTR(frustum);
+  if (calib_host == nullptr) {
+    LSS_CHECK_PTR(inv_post_rots); LSS_CHECK_PTR(post_trans); LSS_CHECK_PTR(combine); LSS_CHECK_PTR(trans);
+  } else if (B * N > CAL_MAX) {
+    return LSS_E_SHAPE;
+  }
+  LSS_CHECK_PTR(dx); LSS_CHECK_PTR(bx); LSS_CHECK_PTR(voxel); LSS_CHECK_PTR(x);
   LSS_CHECK_PTR(w); LSS_CHECK_PTR(bias); LSS_CHECK_PTR(depth); LSS_CHECK_PTR(feat);
   LSS_CHECK_POS(B); LSS_CHECK_POS(N); LSS_CHECK_POS(D); LSS_CHECK_POS(fH); LSS_CHECK_POS(fW);
   LSS_CHECK_POS(X); LSS_CHECK_POS(Y); LSS_CHECK_POS(Z); LSS_CHECK_POS(Cin); LSS_CHECK_POS(C);
@@ -333,9 +376,18 @@ extern "C" int lss_depthnet_voxels_fwd(const float* frustum, const float* inv_po
   const int NT = (D + C + 15) / 16;
   const size_t lds_bytes = (size_t)5 * NT * 16 * lss_depthnet::LDS_LD * sizeof(float);
   hipStream_t st = lss_stream(stream);
-#define LSS_F_CASE(n)                                                                                       \
-  case n:                                                                                                   \
-    hipLaunchKernelGGL(depthnet_and_voxels_kernel<n>, dim3((unsigned)nblk), dim3(256), lds_bytes, st, a); \
+  CalInline cal;
+  if (calib_host != nullptr) {
+    cal.n = B * N;
+    for (int i = 0; i < B * N * 24; ++i) cal.v[i] = calib_host[i];
+  }
+#define LSS_F_CASE(n)                                                                                          \
+  case n:                                                                                                      \
+    if (calib_host != nullptr)                                                                                 \
+      hipLaunchKernelGGL(depthnet_and_voxels_hostcal_kernel<n>, dim3((unsigned)nblk), dim3(256), lds_bytes, st, a, \
+                         cal);                                                                                 \
+    else                                                                                                       \
+      hipLaunchKernelGGL(depthnet_and_voxels_kernel<n>, dim3((unsigned)nblk), dim3(256), lds_bytes, st, a);    \
     break;
   switch (NT) {
     LSS_F_CASE(1) LSS_F_CASE(2) LSS_F_CASE(3) LSS_F_CASE(4) LSS_F_CASE(5) LSS_F_CASE(6) LSS_F_CASE(7) LSS_F_CASE(8)
@@ -344,4 +396,25 @@ extern "C" int lss_depthnet_voxels_fwd(const float* frustum, const float* inv_po
   }
 #undef LSS_F_CASE
   return lss_launch_status();
+}
+
+extern "C" int lss_depthnet_voxels_fwd(const float* frustum, const float* inv_post_rots, const float* post_trans,
+                                       const float* combine, const float* trans, const float* dx, const float* bx,
+                                       const float* x, const float* w, const float* bias, int B, int N, int D, int fH,
+                                       int fW, int Cin, int C, int X, int Y, int Z, int32_t* voxel,
+                                       int32_t* vox_count, float* depth, float* feat, void* stream) {
+  return depthnet_voxels_impl(frustum, inv_post_rots, post_trans, combine, trans, nullptr, dx, bx, x, w, bias, B, N, D,
+                              fH, fW, Cin, C, X, Y, Z, voxel, vox_count, depth, feat, stream);
+}
+
+// calib_host: HOST pointer to B*N*24 floats laid out [inv_post_rots (B*N*9) | combine (B*N*9) | post_trans (B*N*3) |
+// trans (B*N*3)] (= data.CalibrationPack.buffer); read during this call and shipped inside the kernel arguments.
+extern "C" int lss_depthnet_voxels_hostcal_fwd(const float* frustum, const float* calib_host, const float* dx,
+                                               const float* bx, const float* x, const float* w, const float* bias,
+                                               int B, int N, int D, int fH, int fW, int Cin, int C, int X, int Y,
+                                               int Z, int32_t* voxel, int32_t* vox_count, float* depth, float* feat,
+                                               void* stream) {
+  LSS_CHECK_PTR(calib_host);
+  return depthnet_voxels_impl(frustum, nullptr, nullptr, nullptr, nullptr, calib_host, dx, bx, x, w, bias, B, N, D, fH,
+                              fW, Cin, C, X, Y, Z, voxel, vox_count, depth, feat, stream);
 }

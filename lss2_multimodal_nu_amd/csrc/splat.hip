@@ -397,15 +397,19 @@ extern "C" int lss_lift_splat_bwd(const void* grad_bev, int layout, const int32_
   return lss_launch_status();
 }
 
-extern "C" int lss_lift_splat_forward(const float* frustum, const float* inv_post_rots,
-                                      const float* post_trans, const float* combine, const float* trans,
-                                      const float* dx, const float* bx, const float* x, const float* w,
-                                      const float* bias, int B, int N, int D, int fH, int fW, int Cin,
-                                      int C, int X, int Y, int Z, int32_t* voxel, int32_t* vox_count,
-                                      int32_t* vox_list, int32_t* entries, int32_t* cursor, float* depth,
-                                      float* feat, void* bev, int layout, int math, void* stream) {
+static int lift_splat_forward_impl(const float* frustum, const float* inv_post_rots, const float* post_trans,
+                                   const float* combine, const float* trans, const float* calib_host, const float* dx,
+                                   const float* bx, const float* x, const float* w, const float* bias, int B, int N,
+                                   int D, int fH, int fW, int Cin, int C, int X, int Y, int Z, int32_t* voxel,
+                                   int32_t* vox_count, int32_t* vox_list, int32_t* entries, int32_t* cursor,
+                                   float* depth, float* feat, void* bev, int layout, int math, void* stream) {
   int rc;
-  if (math == LSS_DT_F32 && getenv("LSS_NO_K2K3") == nullptr) {
+  if (calib_host != nullptr) {
+    if (math != LSS_DT_F32) return LSS_E_LAYOUT;
+    rc = lss_depthnet_voxels_hostcal_fwd(frustum, calib_host, dx, bx, x, w, bias, B, N, D, fH, fW, Cin, C, X, Y, Z,
+                                         voxel, vox_count, depth, feat, stream);
+    if (rc) return rc;
+  } else if (math == LSS_DT_F32 && getenv("LSS_NO_K2K3") == nullptr) {
     // K2 || K3 as one launch (independent, both latency-bound)
     rc = lss_depthnet_voxels_fwd(frustum, inv_post_rots, post_trans, combine, trans, dx, bx, x, w, bias, B, N, D, fH,
                                  fW, Cin, C, X, Y, Z, voxel, vox_count, depth, feat, stream);
@@ -421,4 +425,30 @@ extern "C" int lss_lift_splat_forward(const float* frustum, const float* inv_pos
                          entries, cursor, stream);
   if (rc) return rc;
   return lss_lift_splat_fwd(feat, vox_list, entries, B, N, D, fH, fW, C, X, Y, Z, bev, layout, stream);
+}
+
+extern "C" int lss_lift_splat_forward(const float* frustum, const float* inv_post_rots,
+                                      const float* post_trans, const float* combine, const float* trans,
+                                      const float* dx, const float* bx, const float* x, const float* w,
+                                      const float* bias, int B, int N, int D, int fH, int fW, int Cin,
+                                      int C, int X, int Y, int Z, int32_t* voxel, int32_t* vox_count,
+                                      int32_t* vox_list, int32_t* entries, int32_t* cursor, float* depth,
+                                      float* feat, void* bev, int layout, int math, void* stream) {
+  return lift_splat_forward_impl(frustum, inv_post_rots, post_trans, combine, trans, nullptr, dx, bx, x, w, bias, B, N,
+                                 D, fH, fW, Cin, C, X, Y, Z, voxel, vox_count, vox_list, entries, cursor, depth, feat,
+                                 bev, layout, math, stream);
+}
+
+// The same with the calibration handed over as ONE HOST buffer (layout of lss_depthnet_voxels_hostcal_fwd,
+// B*N <= 36, f32 depthnet math): it travels inside the kernel arguments - no H2D copy, no staging.
+extern "C" int lss_lift_splat_forward_hostcal(const float* frustum, const float* calib_host, const float* dx,
+                                              const float* bx, const float* x, const float* w, const float* bias,
+                                              int B, int N, int D, int fH, int fW, int Cin, int C, int X, int Y,
+                                              int Z, int32_t* voxel, int32_t* vox_count, int32_t* vox_list,
+                                              int32_t* entries, int32_t* cursor, float* depth, float* feat,
+                                              void* bev, int layout, void* stream) {
+  LSS_CHECK_PTR(calib_host);
+  return lift_splat_forward_impl(frustum, nullptr, nullptr, nullptr, nullptr, calib_host, dx, bx, x, w, bias, B, N, D,
+                                 fH, fW, Cin, C, X, Y, Z, voxel, vox_count, vox_list, entries, cursor, depth, feat,
+                                 bev, layout, LSS_DT_F32, stream);
 }

@@ -18,6 +18,8 @@ What is NOT here: the EfficientNet-B4 trunk (`Encoder`, third-party weights, a
 network fetch).  `encoder=` accepts any module producing the (B*N, 512, fH, fW)
 trunk features; the default passes such features straight through.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -159,6 +161,20 @@ class _LiftSplatMixin:
         host time.  `data.prepare_calibration` does the same in the loader instead."""
         return calib_matrices(rots, intrins, post_rots)
 
+    def _host_calib(self, rots, trans, intrins, post_rots, post_trans, ncams):
+        """The B*N*24-float host buffer [inv_post_rots | combine | post_trans | trans] when the calibration
+        lives on the CPU (DataLoader tensors or a CalibrationPack) and is small enough to travel in the kernel
+        arguments; None otherwise (GPU-resident calibration keeps the device-pointer path)."""
+        if ncams > ops.HOSTCAL_MAX_CAMS or os.environ.get("LSS_NO_HOSTCAL"):
+            return None
+        if isinstance(rots, CalibrationPack):
+            return rots.buffer
+        if any(t.is_cuda for t in (rots, trans, intrins, post_rots, post_trans)):
+            return None
+        inv_pr, comb = self._calib_matrices(rots, intrins, post_rots)
+        return torch.cat([inv_pr.reshape(-1), comb.reshape(-1), post_trans.detach().float().reshape(-1),
+                          trans.detach().float().reshape(-1)])
+
     def _device_calib(self, dev, rots, trans, intrins, post_rots, post_trans):
         """(inv_post_rots, combine, post_trans, trans) on the device.  A `CalibrationPack` passed as
         `rots` (built by the DataLoader, data.prepare_calibration) skips the host linear algebra: its
@@ -257,8 +273,16 @@ class _LiftSplatMixin:
         # inference: K3 -> K2 -> K4 -> K5 through one native call
         dev = self.frustum.device
         nx = self._nx_ints()
-        inv_pr, comb, ptr, trn = self._device_calib(dev, rots, trans, intrins, post_rots, post_trans)
         ws = self._workspace(B * dims[1] * self.D * fH * fW, B * nx[0] * nx[1] * nx[2], dev)
+        host = self._host_calib(rots, trans, intrins, post_rots, post_trans, BN) if ce.math == "fp32" else None
+        if host is not None:
+            # host calibration rides in the kernel arguments: no H2D copy, no staging buffer
+            with ops.region("lift_splat_level"):
+                bev, _, _ = ops.lift_splat_forward_hostcal(self.frustum.detach(), host, self.dx.detach(), self.bx.detach(),
+                                                           x.float().contiguous(), ce.depthnet.weight.detach(),
+                                                           ce.depthnet.bias.detach(), ws, dims, nx, layout)
+            return bev
+        inv_pr, comb, ptr, trn = self._device_calib(dev, rots, trans, intrins, post_rots, post_trans)
         with ops.region("lift_splat_level"):
             bev, _, _ = ops.lift_splat_forward(self.frustum.detach(), inv_pr, ptr, comb, trn, self.dx.detach(),
                                                self.bx.detach(), x.float().contiguous(), ce.depthnet.weight.detach(),

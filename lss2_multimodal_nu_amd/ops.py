@@ -321,6 +321,43 @@ def lift_splat_forward(frustum, inv_post_rots, post_trans, combine, trans, dx, b
     return out, depth, feat
 
 
+HOSTCAL_MAX_CAMS = 36
+
+
+def lift_splat_forward_hostcal(frustum, calib_host, dx, bx, x, weight, bias, ws, dims, nx, layout=BEV_NCHW_F32):
+    """lift_splat_forward with the calibration as ONE CPU fp32 buffer of B*N*24 floats
+    ([inv_post_rots | combine | post_trans | trans] = data.CalibrationPack.buffer): it is read during the
+    call and rides in the kernel arguments - no H2D copy.  B*N <= HOSTCAL_MAX_CAMS; f32 depthnet math."""
+    B, Ncam, D, fH, fW, C = dims
+    X, Y, Z = nx
+    if calib_host.is_cuda or calib_host.dtype != torch.float32 or not calib_host.is_contiguous() \
+            or calib_host.numel() != B * Ncam * 24 or B * Ncam > HOSTCAL_MAX_CAMS:
+        raise ValueError("calib_host must be a contiguous CPU fp32 buffer of B*N*24 floats (B*N <= %d)" % HOSTCAL_MAX_CAMS)
+    for t, name, shp in ((frustum, "frustum", (D, fH, fW, 3)), (dx, "dx", (3,)), (bx, "bx", (3,))):
+        _f32c(t, name, shp)
+    Cin = x.shape[1]
+    _f32c(x, "x", (B * Ncam, Cin, fH, fW))
+    w2 = weight.reshape(weight.shape[0], -1)
+    _f32c(w2, "depthnet.weight", (D + C, Cin))
+    _f32c(bias, "depthnet.bias", (D + C,))
+    if ws.P != B * Ncam * D * fH * fW or ws.nvox != B * X * Y * Z:
+        raise ValueError("workspace does not match dims")
+    dev = x.device
+    depth = torch.empty(B * Ncam, D, fH, fW, dtype=torch.float32, device=dev)
+    feat = torch.empty(B * Ncam, fH, fW, C, dtype=torch.float32, device=dev)
+    if layout == BEV_NCHW_F32:
+        bev = torch.empty(B, Z * C, X, Y, dtype=torch.float32, device=dev)
+        out = bev
+    else:
+        bev = torch.empty(B, X, Y, Z * C, dtype=torch.float32 if layout == BEV_NHWC_F32 else torch.bfloat16, device=dev)
+        out = bev.permute(0, 3, 1, 2)
+    N.check(N.lib().lss_lift_splat_forward_hostcal(
+        N.ptr(frustum), calib_host.data_ptr(), N.ptr(dx), N.ptr(bx), N.ptr(x), N.ptr(w2), N.ptr(bias), B, Ncam, D, fH, fW,
+        Cin, C, X, Y, Z, N.ptr(ws.voxel), N.ptr(ws.vox_count), N.ptr(ws.vox_list), N.ptr(ws.entries), N.ptr(ws.cursor),
+        N.ptr(depth), N.ptr(feat), N.ptr(bev), layout, N.stream()), "lss_lift_splat_forward_hostcal")
+    return out, depth, feat
+
+
 def lift_splat_bwd(grad_bev, voxel, depth, feat, dims, nx):
     """K7.  grad_bev logical (B, Z*C, X, Y), contiguous or channels_last fp32.
     Returns g_logits (BN, D+C, fH, fW)."""

@@ -293,6 +293,45 @@ def test_forward_with_loader_side_calibration_pack_is_bitwise_identical(model, g
     assert torch.equal(a, b) and torch.equal(ya, yb)
 
 
+def test_host_calibration_in_kernel_arguments_is_bitwise_identical(model, golden, monkeypatch):
+    """CPU calibration (B*N <= 36) travels inside the kernel arguments of the fused K2||K3 launch; GPU-resident
+    calibration and LSS_NO_HOSTCAL use the device-pointer path.  Same bits either way (exact-index contract)."""
+    g = golden("g3_train_b1_s0")
+    calib = [torch.from_numpy(g[k]) for k in ("rots", "trans", "intrins", "post_rots", "post_trans")]
+    torch.manual_seed(12)
+    x = torch.randn(6, 512, 8, 22).cuda()
+    with torch.no_grad():
+        nx = model._nx_ints()
+        ws = model._workspace(6 * model.D * 8 * 22, nx[0] * nx[1] * nx[2], x.device)
+        y_host = model(x, *calib)
+        v_host = ws.voxel.clone()
+        monkeypatch.setenv("LSS_NO_HOSTCAL", "1")
+        y_ptr = model(x, *calib)
+        v_ptr = ws.voxel.clone()
+        monkeypatch.delenv("LSS_NO_HOSTCAL")
+        y_dev = model(x, *[c.cuda() for c in calib])
+    assert torch.equal(v_host, v_ptr)
+    assert torch.equal(y_host, y_ptr) and torch.equal(y_host, y_dev)
+
+
+def test_host_calibration_argument_checks():
+    from lss2_multimodal_nu_amd import ops
+    ws = ops.SplatWorkspace(1 * 1 * 4 * 2 * 2, 8 * 8 * 1, "cuda")
+    fr = torch.zeros(4, 2, 2, 3).cuda()
+    dx, bx = torch.ones(3).cuda(), torch.zeros(3).cuda()
+    x = torch.zeros(1, 64, 2, 2).cuda()
+    w, b = torch.zeros(4 + 64, 64, 1, 1).cuda(), torch.zeros(68).cuda()
+    dims, nx = (1, 1, 4, 2, 2, 64), (8, 8, 1)
+    with pytest.raises(ValueError):  # wrong length
+        ops.lift_splat_forward_hostcal(fr, torch.zeros(23), dx, bx, x, w, b, ws, dims, nx)
+    with pytest.raises(ValueError):  # device buffer
+        ops.lift_splat_forward_hostcal(fr, torch.zeros(24).cuda(), dx, bx, x, w, b, ws, dims, nx)
+    eye = torch.eye(3).reshape(-1)
+    cal = torch.cat([eye, eye, torch.zeros(6)])
+    bev, depth, feat = ops.lift_splat_forward_hostcal(fr, cal, dx, bx, x, w, b, ws, dims, nx)
+    assert bev.shape == (1, 64, 8, 8) and torch.isfinite(bev).all()
+
+
 @pytest.mark.parametrize("C", [4, 7])
 def test_weighted_cross_entropy_fused_vs_torch(C):
     """SimpleLoss / MultiLoss' BEV term, forward and backward, incl. ignored pixels."""
