@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblss_hip.so")
+# LSS_HIP_LIB: another build of the same ABI (developer A/B runs of two kernel versions on one box)
+LIB_PATH = os.environ.get("LSS_HIP_LIB") or os.path.join(_HERE, "csrc", "liblss_hip.so")
 
 BEV_NCHW_F32, BEV_NHWC_F32, BEV_NHWC_BF16 = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1

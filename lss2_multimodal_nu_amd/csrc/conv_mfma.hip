@@ -56,7 +56,15 @@ struct ConvArgs {
   const float* head_b;
   float* head_out;
   int head_n;
+  // diagnostics (tools/conv_phase_stamps.py): 8 x 100-MHz s_memrealtime stamps per workgroup, or null
+  unsigned long long* stamps;
 };
+
+// LSS_CONV_STAMPS=<hex device address of a u64 buffer, 8 entries per workgroup> switches the phase stamps on
+static unsigned long long* conv_stamps_from_env() {
+  const char* e = getenv("LSS_CONV_STAMPS");
+  return e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 16)) : nullptr;
+}
 
 __device__ __forceinline__ float conv_act(float v, int act) {
   if (act == 1) return fmaxf(v, 0.f);
@@ -377,6 +385,11 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
   const int oy0 = ty * TH, ox0 = tx * TW, n0 = blockIdx.y * BN;
   const int wc = wave % WCOLS, wr = wave / WCOLS;
   const int prow0 = wr * (2 * RT);
+  auto stamp = [&](int k) {
+    if (a.stamps != nullptr && threadIdx.x == 0)
+      a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = __builtin_amdgcn_s_memrealtime();
+  };
+  stamp(0);
 
   int aoff[RT], boff[2][4];
 #pragma unroll
@@ -558,6 +571,7 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
   else gather_in(0, true);
   wait_vmcnt<0>();
   lds_barrier();
+  stamp(1);
 
   // Main loop.  The NT taps of a chunk are fully unrolled (static patch offsets and
   // fragment double buffer); the ring slot advances at run time.  Rolling prefetch:
@@ -632,6 +646,7 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
   // free now) -> every thread picks up 8 consecutive channels of a pixel, adds the
   // residual (one 16-B load), ReLU, rounds to bf16 once, and stores 16 B.
   float* otile = reinterpret_cast<float*>(smem);
+  stamp(2);
   // (the loop's final lds_barrier already guarantees every wave is done reading LDS)
   if (KSP == 2) {
     // split-K: the second group's partial sums meet the first group's through LDS (same lane ->
@@ -661,79 +676,94 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
     }
     lds_barrier();  // the partials are consumed before group 0 restages the tile below
   }
-  // residual rows of this thread's output pieces: issued BEFORE the accumulators are staged, so
-  // the loads fly during the LDS write / barrier / read-back instead of stalling the store loop
-  constexpr int EPI = (TH * 16 * (BN / 8) + 255) / 256;
-  uint4 rres[EPI];
-  {
-    const unsigned short* resp = reinterpret_cast<const unsigned short*>(a.residual);
-#pragma unroll
-    for (int it = 0; it < EPI; ++it) {
-      // piece `it` of this thread: half it / (EPI/EPH), piece tid + 256 * (it % (EPI/EPH)) within the half
-      const int e = (it / (EPI / EPH)) * ((TH / EPH) * 16 * (BN / 8)) + tid + (it % (EPI / EPH)) * 256;
-      const int pl = e / (BN / 8), c8 = e % (BN / 8);
-      const int oy = oy0 + (pl >> 4), ox = ox0 + (pl & 15);
-      const int co = n0 + c8 * 8;
-      rres[it] = make_uint4(0, 0, 0, 0);
-      if (grp == 0 && resp && !a.head_out && tid + (it % (EPI / EPH)) * 256 < (TH / EPH) * 16 * (BN / 8) && oy < a.Ho &&
-          ox < a.Wo && co + 8 <= a.Cout && (a.Cout & 7) == 0)
-        rres[it] = *reinterpret_cast<const uint4*>(resp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + co);
-    }
-  }
-  // EPH = 2 (KC = 32): the tile is staged and stored in two halves of TH/2 rows, so the staging
-  // area fits the 39 KB the main loop used (three workgroups per CU)
-  constexpr int HROWS = TH / EPH;                       // image rows per staged half
-  constexpr int HPIECES = HROWS * 16 * (BN / 8);        // 16-B output pieces per half
-  static_assert(EPI % EPH == 0 && HPIECES % 256 == 0 || EPH == 1, "half tiles split evenly over the threads");
+  // Output pieces of this thread.  A piece = 8 consecutive channels (16 B of bf16) of one pixel;
+  // 256 threads cover PPJ pixels x CG channel groups per pass, so a thread's pixel column, channel
+  // group and first row never change: every per-pass address is one base + a compile-time offset
+  // (the epilogue of the launch-bound layers is instruction-issue time, not bandwidth).
+  constexpr int CG = BN / 8;              // 16-B channel groups per pixel
+  constexpr int PPJ = 256 / CG;           // pixels per pass
+  constexpr int RPJ = PPJ / 16;           // image rows per pass
+  constexpr int HROWS = TH / EPH;         // image rows per staged half (EPH = 2: KC = 32, see OUT_BYTES)
+  constexpr int HPIECES = HROWS * 16 * CG;
+  constexpr int EPJ = HPIECES / 256;      // passes per half
+  static_assert(HPIECES % 256 == 0 && PPJ % 16 == 0, "half tiles split evenly over the threads");
+  const int pix0 = tid / CG, c8 = tid % CG;
+  const int ox = ox0 + (pix0 & 15), oyb = oy0 + (pix0 >> 4);
+  const int co = n0 + c8 * 8;
   // dual-output launches: this workgroup's channel block belongs to y (columns [0, split)) or y2
   const bool second = a.y2 != nullptr && n0 >= a.split;
   const int ycol0 = second ? a.split : 0;                                   // first channel of the tensor
   const int ycw = a.y2 == nullptr ? a.Cout : (second ? a.Cout - a.split : a.split);  // its channel count
   const int eact = n0 < a.relu_n ? a.relu : 0;
-  unsigned short* y = reinterpret_cast<unsigned short*>(second ? a.y2 : a.y);
+  const bool vec_ok = (ycw & 7) == 0 && co + 8 <= a.Cout;  // 16-B aligned, whole channel group
+  const bool col_ok = grp == 0 && ox < a.Wo && co < a.Cout;
+  const size_t pixb = ((size_t)b * a.Ho + oyb) * a.Wo + ox;  // pixel index of pass 0 of half 0
+  const int ystep = a.Wo * ycw, rstep = a.Wo * a.Cout;       // elements per image row
+  // residual rows: issued BEFORE the accumulators are staged, so the loads fly during the LDS
+  // write / barrier / read-back instead of stalling the store loop
+  uint4 rres[EPH * EPJ];
   const unsigned short* res = reinterpret_cast<const unsigned short*>(a.residual);
-  const bool vec_ok = (ycw & 7) == 0;  // 16-B aligned channel groups
+  const bool res_vec = res != nullptr && !a.head_out && col_ok && (a.Cout & 7) == 0 && co + 8 <= a.Cout;
+  {
+    const unsigned short* rb = res + pixb * a.Cout + co;
+#pragma unroll
+    for (int it = 0; it < EPH * EPJ; ++it) {
+      const int row = (it / EPJ) * HROWS + (it % EPJ) * RPJ;
+      rres[it] = make_uint4(0, 0, 0, 0);
+      if (res_vec && oyb + row < a.Ho) rres[it] = *reinterpret_cast<const uint4*>(rb + row * rstep);
+    }
+  }
+  unsigned short* y = reinterpret_cast<unsigned short*>(second ? a.y2 : a.y);
+  const size_t obase = pixb * ycw + (co - ycol0);
   const __amdgpu_buffer_rsrc_t yrsrc =
       __builtin_amdgcn_make_buffer_rsrc(y, 0, a.wt ? (int)((size_t)a.M * ycw * 2) : 0, 0x00020000);
+  // staging address of this lane: D[row = (i&3) + 8*(i>>2) + 4*h][col = r], and (i&3) + 4*h < 16, so
+  // pixel = (2*rt + (i>>3))*16 + (i&3) + 8*((i>>2)&1) + 4*h: lane part + compile-time part
+  float* const ost = otile + (prow0 * 16 + 4 * h) * OLD + wc * 64 + r;
 #pragma unroll
   for (int half = 0; half < EPH; ++half) {
     const bool mine = grp == 0 && (EPH == 1 || (prow0 / HROWS) == half);  // this wave's rows belong to the half
     if (mine) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        const int cl = wc * 64 + ct * 32 + r;  // channel within the tile
-        const int co = n0 + cl;
-        const bool cok = co < a.Cout;
         const float sc = esc[ct], sh = esh[ct];
-        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-            const int pl = (prow0 - half * HROWS + 2 * rt + (row >> 4)) * 16 + (row & 15);  // pixel within the half
-            const float raw = acc[rt][ct][i];
-            otile[pl * OLD + cl] = raw * sc + sh;
-            if (a.stats) {
-              const int oy = oy0 + half * HROWS + (pl >> 4), ox = ox0 + (pl & 15);
-              if (cok && oy < a.Ho && ox < a.Wo) {
+            const int pc = (2 * rt + (i >> 3)) * 16 + (i & 3) + 8 * ((i >> 2) & 1) - half * HROWS * 16;
+            ost[pc * OLD + ct * 32] = acc[rt][ct][i] * sc + sh;
+          }
+      }
+      if (a.stats) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const int cs = n0 + wc * 64 + ct * 32 + r;
+          const bool cok = cs < a.Cout;
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+              const int sy = oy0 + prow0 + 2 * rt + (row >> 4), sx = ox0 + (row & 15);
+              if (cok && sy < a.Ho && sx < a.Wo) {
+                const float raw = acc[rt][ct][i];
                 s1 += raw;
                 s2 += raw * raw;
               }
             }
-          }
-        }
-        if (a.stats) {
           s1 += __shfl_xor(s1, 32, 64);
           s2 += __shfl_xor(s2, 32, 64);
           if (h == 0 && cok) {
-            atomicAdd(a.stats + co, s1);
-            atomicAdd(a.stats + a.Cout + co, s2);
+            atomicAdd(a.stats + cs, s1);
+            atomicAdd(a.stats + a.Cout + cs, s2);
           }
         }
       }
     }
     lds_barrier();
+    if (half == 0) stamp(3);
     if (grp != 0) {
       // second K-split group: its sums were handed over above; it only keeps the barriers company
     } else if (a.head_out) {
@@ -741,50 +771,50 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
       // their partial dot products with shuffles; the activation itself is never stored
       if (BN == 128) {
         for (int e = tid; e < HROWS * 16 * 16; e += 256) {
-          const int pl = e >> 4, c8 = e & 15;
-          const int oy = oy0 + half * HROWS + (pl >> 4), ox = ox0 + (pl & 15);
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8);
-          const f32x4 v1 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8 + 4);
+          const int pl = e >> 4, hc8 = e & 15;
+          const int oy = oy0 + half * HROWS + (pl >> 4), hx = ox0 + (pl & 15);
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + hc8 * 8);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + hc8 * 8 + 4);
           float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
           if (a.relu) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
           }
           for (int k = 0; k < a.head_n; ++k) {
-            const float* hw = a.head_w + k * BN + c8 * 8;
+            const float* hw = a.head_w + k * BN + hc8 * 8;
             float part = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) part = fmaf(v[j], hw[j], part);
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-            if (c8 == 0 && oy < a.Ho && ox < a.Wo)
-              a.head_out[(((size_t)b * a.head_n + k) * a.Ho + oy) * a.Wo + ox] = part + a.head_b[k];
+            if (hc8 == 0 && oy < a.Ho && hx < a.Wo)
+              a.head_out[(((size_t)b * a.head_n + k) * a.Ho + oy) * a.Wo + hx] = part + a.head_b[k];
           }
         }
       }
-    } else {
+    } else if (col_ok) {
+      const float* const ord = otile + pix0 * OLD + c8 * 8;
 #pragma unroll
-      for (int j = 0; j < EPI / EPH; ++j) {
-        const int it = half * (EPI / EPH) + j;  // index into the prefetched residual pieces
-        const int e = tid + j * 256;            // piece within the half
-        if (e >= HPIECES) continue;
-        const int pl = e / (BN / 8), c8 = e % (BN / 8);
-        const int oy = oy0 + half * HROWS + (pl >> 4), ox = ox0 + (pl & 15);
-        const int co = n0 + c8 * 8;
-        if (oy >= a.Ho || ox >= a.Wo || co >= a.Cout) continue;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + c8 * 8 + 4);
+      for (int j = 0; j < EPJ; ++j) {
+        const int row = half * HROWS + j * RPJ;  // image row of this pass relative to oyb
+        if (oyb + row >= a.Ho) continue;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ord + j * PPJ * OLD);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(ord + j * PPJ * OLD + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ycw + (co - ycol0);
-        if (vec_ok && co + 8 <= a.Cout) {
-          if (res) {
-            const uint4 rv = rres[it];
+        const size_t o = obase + (size_t)(row * ystep);
+        if (vec_ok) {
+          if (res_vec) {
+            const uint4 rv = rres[half * EPJ + j];
             const unsigned int ru[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               v[2 * k] += lss_bf2f((unsigned short)(ru[k] & 0xffff));
               v[2 * k + 1] += lss_bf2f((unsigned short)(ru[k] >> 16));
             }
+          } else if (res) {
+            const unsigned short* rp = res + (pixb * a.Cout + co) + (size_t)(row * rstep);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += lss_bf2f(rp[k]);
           }
           if (eact == 1) {
 #pragma unroll
@@ -794,7 +824,7 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
             for (int k = 0; k < 8; ++k) v[k] = conv_act(v[k], 2);
           }
           if (a.out_f32) {
-            float* yf = reinterpret_cast<float*>(a.y) + o;
+            float* yf = reinterpret_cast<float*>(second ? a.y2 : a.y) + o;
             *reinterpret_cast<f32x4*>(yf) = (f32x4){v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(yf + 4) = (f32x4){v[4], v[5], v[6], v[7]};
           } else {
@@ -811,17 +841,24 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
             }
           }
         } else {
+          // ragged channel counts: element by element
+          const size_t ro = (pixb * a.Cout + co) + (size_t)(row * rstep);
           for (int k = 0; k < 8 && co + k < a.Cout; ++k) {
             float t = v[k];
-            if (res) t += lss_bf2f(res[o + k]);
+            if (res) t += lss_bf2f(res[ro + k]);
             t = conv_act(t, eact);
-            if (a.out_f32) reinterpret_cast<float*>(a.y)[o + k] = t;
+            if (a.out_f32) reinterpret_cast<float*>(second ? a.y2 : a.y)[o + k] = t;
             else y[o + k] = lss_f2bf(t);
           }
         }
       }
     }
     if (half + 1 < EPH) lds_barrier();  // everyone has read this half before the next one is staged
+  }
+  if (a.stamps != nullptr) {
+    stamp(4);
+    wait_vmcnt<0>();  // stores acknowledged
+    stamp(5);
   }
 }
 
@@ -977,6 +1014,7 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   // K blocks never straddle the x2 | upsample(x) boundary
   if (Cx % kblock != 0 || C2 % kblock != 0) return LSS_E_SHAPE;
   ConvArgs a;
+  a.stamps = conv_stamps_from_env();
   a.x = x; a.x2 = x2; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = residual;
   a.y = y; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cx = Cx; a.C2 = C2; a.up = up;
@@ -1038,6 +1076,7 @@ static int conv2d_s2_impl(const void* x, const void* w_s2d, const float* scale, 
   if (!((K == 3 && pad == 1) || (K == 7 && pad == 3) || (K == 1 && pad == 0))) return LSS_E_SHAPE;
   if (Cx % 64 != 0) return LSS_E_SHAPE;
   ConvArgs a;
+  a.stamps = conv_stamps_from_env();
   a.x = x; a.x2 = nullptr; a.w = w_s2d; a.scale = scale; a.shift = shift; a.residual = residual;
   a.y = y; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cx = Cx; a.C2 = 0; a.up = 1;
@@ -1102,6 +1141,7 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
   if (Cout != 128 || C2 < 0 || Cx % 64 != 0 || C2 % 64 != 0 || head_n > 64) return LSS_E_SHAPE;
   if (C2 > 0 && x2 == nullptr) return LSS_E_NULL;
   ConvArgs a;
+  a.stamps = conv_stamps_from_env();
   a.x = x; a.x2 = x2; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = nullptr;
   a.y = nullptr; a.stats = nullptr;
   a.B = B; a.H = H; a.W = W; a.Cx = Cx; a.C2 = C2; a.up = up;

@@ -73,6 +73,46 @@ def main():
             tot_fl += fl * n
             print("%-22s %10.1f %10.2f %8.1f   x%d" % (name, us, fl / 1e9, fl / us / 1e6, n))
         print("%-22s %10.1f %10.2f %8.1f" % ("BevEncode total", tot_us, tot_fl / 1e9, tot_fl / tot_us / 1e6))
+    if args.only == "stamps":
+        # in-kernel phase stamps of the LDS-tiled conv (100-MHz s_memrealtime, 8 per workgroup):
+        # where a launch's microseconds go - start ramp, prologue, main loop, epilogue, store drain
+        import numpy as np
+        print("%-22s %5s %7s | %s" % ("conv (B=%d)" % B, "WGs", "evt us",
+                                     "start-spread  prologue  loop  stage  stores  drain | first->last us (p50 / max over WGs)"))
+        for name, H, W, Cx, Cout, k, st, pad, C2, up, res in CONVS:
+            if k == 1:
+                continue
+            x = torch.randn(B, H, W, Cx, device="cuda").to(torch.bfloat16)
+            x2 = torch.randn(B, H * up, W * up, C2, device="cuda").to(torch.bfloat16) if C2 else None
+            s2 = st == 2 and k in (3, 7)
+            wraw = torch.randn(Cout, Cx + C2, k, k, device="cuda") * 0.05
+            w = ops.pack_conv_weight_s2d(wraw, pad) if s2 else ops.pack_conv_weight(wraw, dt)
+            sc, sh = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda")
+            Ho = (H * up + 2 * pad - k) // st + 1
+            Wo = (W * up + 2 * pad - k) // st + 1
+            r = torch.randn(B, Ho, Wo, Cout, device="cuda").to(torch.bfloat16) if res else None
+            if s2:
+                fn = lambda: ops.conv2d_s2_nhwc(x, w, k, pad, sc, sh, r, True)
+            else:
+                fn = lambda: ops.conv2d_nhwc(x, w, (k, k), st, pad, sc, sh, r, True, x2, up, None, dt)
+            us = timeit(fn, args.iters)
+            stamps = torch.zeros(8192 * 8, dtype=torch.int64, device="cuda")  # >= any grid here
+            os.environ["LSS_CONV_STAMPS"] = "%x" % stamps.data_ptr()
+            for _ in range(3):
+                stamps.zero_()
+                torch.cuda.synchronize()
+                fn()
+                torch.cuda.synchronize()
+            del os.environ["LSS_CONV_STAMPS"]
+            t = stamps.view(-1, 8).cpu().numpy()
+            t = t[t[:, 0] != 0][:, :6].astype(np.float64) * 0.01  # us
+            t0 = t[:, 0].min()
+            d = np.diff(t, axis=1)
+            f = lambda v: "%5.2f/%5.2f" % (np.median(v), v.max())
+            print("%-22s %5d %7.1f | %s  %s  %s  %s  %s  %s | %5.2f / %5.2f" % (
+                name, len(t), us, f(t[:, 0] - t0), f(d[:, 0]), f(d[:, 1]), f(d[:, 2]), f(d[:, 3]), f(d[:, 4]),
+                np.median(t[:, 5] - t0), (t[:, 5] - t0).max()))
+        return
     if args.only in ("", "l1"):
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from oracle import lss_oracle as lo
