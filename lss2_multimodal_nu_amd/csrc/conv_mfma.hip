@@ -58,6 +58,7 @@ struct ConvArgs {
   int head_n;
   // diagnostics (tools/conv_phase_stamps.py): 8 x 100-MHz s_memrealtime stamps per workgroup, or null
   unsigned long long* stamps;
+  int src_lds;  // MODE 1, KC = 32: the low-res source patch of a chunk is staged in LDS (see SRC below)
 };
 
 // LSS_CONV_STAMPS=<hex device address of a u64 buffer, 8 entries per workgroup> switches the phase stamps on
@@ -358,13 +359,25 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
   constexpr int EPH = KC == 32 ? 2 : 1;
   constexpr int OUT_BYTES = (TH / EPH) * 16 * OLD * 4;
   constexpr int GROUP_BYTES = (3 * W_BYTES + IN_BYTES + 1023) / 1024 * 1024;  // ring + patch of one 4-wave group
-  constexpr int SMEM_BYTES = KSP * GROUP_BYTES > OUT_BYTES ? KSP * GROUP_BYTES : OUT_BYTES;
+  // SRC (fused upsample, KC = 32): the low-res pixels a chunk's patch is interpolated from - at most
+  // SRC_H x SRC_W source positions for scale factors >= 2 - are copied ONCE per chunk into LDS by
+  // LDS-DMA while the previous chunk's taps run, and the 4-corner blend then reads LDS: 2 DMA
+  // instructions per wave instead of 12 scattered global loads per thread in the synchronous
+  // chunk-boundary phase (measured: that phase was 17 % of the fused convs).
+  constexpr bool SRC = FUSED && KC == 32;
+  constexpr int SRC_H = (IH - 1) / 2 + 3, SRC_W = (IW - 1) / 2 + 3;  // 7 x 11 for the 10 x 18 patch
+  constexpr int SRC_DMA = SRC ? (SRC_H * SRC_W * PPP + 255) / 256 : 0;  // DMA instructions per wave per chunk
+  constexpr int SRC_BYTES = SRC_DMA * 4096;
+  constexpr int MAIN_BYTES = KSP * GROUP_BYTES > OUT_BYTES ? KSP * GROUP_BYTES : OUT_BYTES;
+  constexpr int SMEM_BYTES = MAIN_BYTES + SRC_BYTES;
   static_assert(SMEM_BYTES <= (KSP == 2 ? 160 : (KC == 32 ? 53 : 80)) * 1024, "workgroups per CU vs 160 KiB of LDS");
+  static_assert(!SRC || NT >= 3, "the source copies retire at tap 2");
   static_assert(KC == 64 || (RT == 2 && BN == 128 && MODE != 2), "KC = 32 is built for the RT = 2, BN = 128 stride-1 tiles");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
   const int grp = KSP == 2 ? (int)(threadIdx.x >> 8) : 0;  // K-split group of this wave
   unsigned char* w_tile = smem + grp * GROUP_BYTES;
   unsigned char* in_tile = w_tile + 3 * W_BYTES;
+  unsigned char* src_tile = smem + MAIN_BYTES;  // SRC only
 
   const int tid = threadIdx.x & 255, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -440,6 +453,20 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
   // the image); g_w = the blend weights as 16-bit fixed point (lx | ly << 16).
   int g_off[FUSED ? IPT : 1];
   unsigned int g_w[FUSED ? IPT : 1];
+  // SRC: g_off holds the BYTE offset of the top-left corner inside src_tile instead (a multiple of
+  // 16, same flags); src_o[i] = element offset of the source pixel this lane's i-th DMA piece copies
+  const bool use_src = SRC && a.src_lds != 0;
+  const int sy0 = (int)(a.ry * (float)max(oy0 - PAD, 0)), sx0 = (int)(a.rx * (float)max(ox0 - PAD, 0));
+  int src_o[SRC ? SRC_DMA : 1];
+  if (SRC) {
+#pragma unroll
+    for (int i = 0; i < SRC_DMA; ++i) {
+      const int q = (i * 4 + wave) * 64 + lane;
+      const int pos = min(q >> PSH, SRC_H * SRC_W - 1), part = q & (PPP - 1);  // pieces past the patch: any valid pixel
+      const int sr = pos / SRC_W, sc = pos - sr * SRC_W;
+      src_o[i] = ((b * a.H + min(sy0 + sr, a.H - 1)) * a.W + min(sx0 + sc, a.W - 1)) * a.Cx + part * 8;
+    }
+  }
   if (FUSED) {
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
@@ -455,8 +482,9 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
           const unsigned int wy = (unsigned int)((sy - (float)y0) * 65536.f + 0.5f);
           const unsigned int wx = (unsigned int)((sx - (float)x0) * 65536.f + 0.5f);
           g_w[i] = min(wx, 65535u) | (min(wy, 65535u) << 16);
-          g_off[i] = (((b * a.H + y0) * a.W + x0) * a.Cx + part * 8) | (x0 < a.W - 1 ? 1 : 0) |
-                     (y0 < a.H - 1 ? 2 : 0) | 4;
+          const int flags = (x0 < a.W - 1 ? 1 : 0) | (y0 < a.H - 1 ? 2 : 0) | 4;
+          if (use_src) g_off[i] = ((((y0 - sy0) * SRC_W + (x0 - sx0)) * PPP + part) * 16) | flags;
+          else g_off[i] = (((b * a.H + y0) * a.W + x0) * a.Cx + part * 8) | flags;
         }
       }
     }
@@ -478,6 +506,15 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
         if (skip) {
           const int iy = oy0 - PAD + py, ix = ox0 - PAD + px;
           v = *reinterpret_cast<const uint4*>(x2p + ((b * a.Hin + iy) * a.Win + ix) * a.C2 + c0 + part * 8);
+        } else if (use_src) {
+          const unsigned char* p00 = src_tile + (g_off[i] & ~15);
+          const int dx = (g_off[i] & 1) ? PPP * 16 : 0, dy = (g_off[i] & 2) ? SRC_W * PPP * 16 : 0;
+          const uint4 q00 = *reinterpret_cast<const uint4*>(p00);
+          const uint4 q01 = *reinterpret_cast<const uint4*>(p00 + dx);
+          const uint4 q10 = *reinterpret_cast<const uint4*>(p00 + dy);
+          const uint4 q11 = *reinterpret_cast<const uint4*>(p00 + dy + dx);
+          v = blend_bf16x8(q00, q01, q10, q11, (float)(g_w[i] & 0xffff) * (1.f / 65536.f),
+                           (float)(g_w[i] >> 16) * (1.f / 65536.f));
         } else {
           const unsigned short* p00 = xp + (g_off[i] & ~7) + (c0 - a.C2);
           const int dx = (g_off[i] & 1) ? dxs : 0, dy = (g_off[i] & 2) ? dys : 0;
@@ -492,6 +529,16 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
       *reinterpret_cast<uint4*>(in_tile + py * IROWB + px * POSB + part * 16) = v;
     }
   };
+
+  // SRC: source pixels of `chunk` -> src_tile (lane l of DMA block k lands at byte k*1024 + l*16)
+  auto issue_src = [&](int chunk) {
+    const unsigned short* xp = reinterpret_cast<const unsigned short*>(a.x);
+    const int cx = (cbase + chunk) * KC - a.C2;
+#pragma unroll
+    for (int i = 0; i < (SRC ? SRC_DMA : 0); ++i) glds16(xp + src_o[i] + cx, src_tile + (i * 4 + wave) * 1024);
+  };
+  // does `chunk` read the upsampled tensor through src_tile?
+  auto src_chunk = [&](int chunk) { return use_src && chunk < nchunks && (cbase + chunk) * KC >= a.C2; };
 
   // input patch of one 64-channel chunk.  !FUSED: plain 16-B loads, unrolled so they
   // can be parked in registers (prefetch).  FUSED: the 4-corner bilinear gather goes
@@ -565,8 +612,13 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
   }
 
   // prologue: W(0), W(1) on their way; patch of chunk 0
+  if (src_chunk(0)) issue_src(0);
   issue_w(0, 0);
   if (nsteps > 1) issue_w(1, 1);
+  if (src_chunk(0)) {
+    wait_vmcnt<0>();
+    lds_barrier();  // the source pixels of chunk 0 are in LDS for every wave
+  }
   if (FUSED) gather_fused(0);
   else gather_in(0, true);
   wait_vmcnt<0>();
@@ -594,6 +646,7 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
   int slot = 0;  // ring slot of the current step's slab
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const bool last_chunk = chunk + 1 == nchunks;
+    const bool srcq = src_chunk(chunk + 1);  // this chunk's tap 0 also sends the next chunk's source pixels
     read_a(0, 0, 0);
     read_b(0, slot, 0);
 #pragma unroll
@@ -623,6 +676,9 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
         }
         if (more && s4 < WPT) issue_w1(t2, c2, slot2, s4);
       }
+      // after this step's weight pieces, so that (like them) the copies have two steps to land: the
+      // counted waits of tap 0 and tap 1 leave them in flight, the wait of tap 2 retires them
+      if (SRC && tap == 0 && srcq) issue_src(chunk + 1);
       if (prefetch) gather_in(chunk + 1, false);  // next patch -> registers
       if (tap == NT - 1 && !last_chunk) {
         lds_barrier();  // every wave is done with this chunk's patch
@@ -632,6 +688,7 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
       // W(step+1) must have landed in every wave's share before anyone reads it; only the
       // DMA (and patch loads) issued during THIS step may stay in flight
       if (prefetch) wait_vmcnt<WPT + IPT>();
+      else if (SRC && tap < 2 && srcq && more) wait_vmcnt<WPT + SRC_DMA>();
       else if (more) wait_vmcnt<WPT>();
       else wait_vmcnt<0>();
       lds_barrier();
@@ -904,6 +961,14 @@ inline int s2d_taps(int K, int pad) {
   return hi - s2d_tmin(pad) + 1;
 }
 
+// May the KC = 32 fused kernel stage its low-res source pixels in LDS?  Its 10 x 18 patch must map
+// into the SRC_H x SRC_W = 7 x 11 source window: floor(9 ry) + 2 <= 7 and floor(17 rx) + 2 <= 11.
+inline int conv_src_lds_ok(const ConvArgs& a) {
+  if (const char* e = getenv("LSS_CONV_SRC"))
+    if (atoi(e) == 0) return 0;
+  return a.up >= 2 && a.ry * 9.f < 4.99f && a.rx * 17.f < 8.99f;
+}
+
 // Tile selection + launch of conv_lds_kernel.  BN = 64 for narrow layers, else 128; RT = 2
 // (throughput shape) unless that grid would leave the 256 CUs under-filled, in which case
 // half-height workgroups (RT = 1) shorten the per-workgroup critical path instead.
@@ -933,7 +998,9 @@ void launch_conv_lds(const ConvArgs& a, hipStream_t st) {
     if (rt == 2) {
       if constexpr (MODE != 2 && KH == 3) {
         if (kc32) {
-          hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD, 32>), g, dim3(256), 0, st, a, tilesX, tilesY);
+          ConvArgs a32 = a;
+          a32.src_lds = MODE == 1 ? conv_src_lds_ok(a) : 0;
+          hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD, 32>), g, dim3(256), 0, st, a32, tilesX, tilesY);
           return;
         }
       }
@@ -1015,6 +1082,7 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   if (Cx % kblock != 0 || C2 % kblock != 0) return LSS_E_SHAPE;
   ConvArgs a;
   a.stamps = conv_stamps_from_env();
+  a.src_lds = 0;
   a.x = x; a.x2 = x2; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = residual;
   a.y = y; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cx = Cx; a.C2 = C2; a.up = up;
@@ -1077,6 +1145,7 @@ static int conv2d_s2_impl(const void* x, const void* w_s2d, const float* scale, 
   if (Cx % 64 != 0) return LSS_E_SHAPE;
   ConvArgs a;
   a.stamps = conv_stamps_from_env();
+  a.src_lds = 0;
   a.x = x; a.x2 = nullptr; a.w = w_s2d; a.scale = scale; a.shift = shift; a.residual = residual;
   a.y = y; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cx = Cx; a.C2 = 0; a.up = 1;
@@ -1142,6 +1211,7 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
   if (C2 > 0 && x2 == nullptr) return LSS_E_NULL;
   ConvArgs a;
   a.stamps = conv_stamps_from_env();
+  a.src_lds = 0;
   a.x = x; a.x2 = x2; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = nullptr;
   a.y = nullptr; a.stats = nullptr;
   a.B = B; a.H = H; a.W = W; a.Cx = Cx; a.C2 = C2; a.up = up;
@@ -1166,8 +1236,10 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
   // the fused-gather form takes the 32-channel steps (three workgroups per CU), as in launch_conv_lds
   bool kc32 = fused && a.Cx % 32 == 0 && a.C2 % 32 == 0;
   if (const char* e = getenv("LSS_CONV_KC")) kc32 = kc32 && atoi(e) == 32;
-  if (fused && kc32)
+  if (fused && kc32) {
+    a.src_lds = conv_src_lds_ok(a);
     hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1, 32>), g, dim3(256), 0, st, a, tilesX, tilesY);
+  }
   else if (fused)
     hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
   else
