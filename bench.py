@@ -203,7 +203,7 @@ def main():
                                ("BASELINE configs[4] per-GPU shapes: batch=%d/GPU, 6 cams 704x256, D=60, 400x400x64 BEV "
                                 "-> BevEncode -> 400x400x4" % B),
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d (sample-sharded, no collective)" % world,
-                   "precision": args.precision, "calibration": "CPU tensors per step; 3x3 inverses on host (exact-index contract), 1.7 KB H2D"},
+                   "precision": args.precision, "calibration": "CPU tensors per step; 3x3 inverses on host (exact-index contract), 576 floats passed in the kernel arguments (no H2D copy)"},
         "roofline": {"kernel": "conv_lds_kernel (+3 conv_direct_kernel): the 18 BevEncode launches of a step, one HIP-event "
                                "bracket around the group (per-launch brackets cost ~10 us of idle each)",
                      "bound": "mfma", "achieved": conv_tf, "peak": peak_tf, "unit": "TFLOP/s",
