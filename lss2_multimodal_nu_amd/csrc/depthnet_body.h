@@ -108,20 +108,41 @@ __device__ __forceinline__ void depthnet_softmax_f32_body(
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int kb = 0; kb < kq; kb += 16) {
-    float xs[4];
+  // Two register sets, software-pipelined: the 4 x loads and NT weight loads of the NEXT 16-deep K
+  // block are in flight while the 4*NT MFMAs of this one issue, so block-start round trips are no
+  // longer exposed.  In-kernel stamps put what remains of the ~13 us K loop at ~5 us of MFMA issue,
+  // ~6 us of weight re-reads through the CU's L1 (every workgroup streams all 215 KB, half a cache
+  // line at a time) and ~1.5 us of x loads.  Per accumulator the k order is the plain loop's:
+  // bitwise the same sums.
+  auto load_block = [&](int kb, float (&xs)[4], f32x4 (&wa)[NT]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) xs[s] = xb[(size_t)(kb + 4 * j + s) * HW];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int n = 16 * t + col;
-      f32x4 wa = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (n < NO) wa = *reinterpret_cast<const f32x4*>(wb + (size_t)n * Cin + kb);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], xs[s], acc[t], 0, 0, 0);
+      wa[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (n < NO) wa[t] = *reinterpret_cast<const f32x4*>(wb + (size_t)n * Cin + kb);
     }
+  };
+  auto mma_block = [&](const float (&xs)[4], const f32x4 (&wa)[NT]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)  // s outer: consecutive MFMAs hit different accumulators (a dependent
+#pragma unroll                   // 16x16x4 f32 pair costs 40 cycles, an independent one 32); per
+      for (int t = 0; t < NT; ++t)  // accumulator the k order is unchanged
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t][s], xs[s], acc[t], 0, 0, 0);
+  };
+  const int nblk = kq >> 4;
+  float xs0[4], xs1[4];
+  f32x4 wa0[NT], wa1[NT];
+  load_block(0, xs0, wa0);
+  int i = 0;
+  for (; i + 2 <= nblk; i += 2) {
+    load_block((i + 1) << 4, xs1, wa1);
+    mma_block(xs0, wa0);
+    if (i + 2 < nblk) load_block((i + 2) << 4, xs0, wa0);
+    mma_block(xs1, wa1);
   }
+  if (i < nblk) mma_block(xs0, wa0);  // odd number of blocks: the last one is already loaded
 
   depthnet_epilogue<NT>(acc, lds, bias, bias + D, D, true, bn, pix0, HW, D, C, depth, feat);
 }
