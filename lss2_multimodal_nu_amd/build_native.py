@@ -26,6 +26,7 @@ SOURCES = {
     "layout.hip": [],
     "bev_transformer.hip": [],
     "linear_mfma.hip": [],
+    "ffn_fused.hip": [],
     "conv_grad.hip": [],
     "bn_train.hip": [],
     "loss.hip": [],

@@ -321,6 +321,28 @@ def lift_splat_forward(frustum, inv_post_rots, post_trans, combine, trans, dx, b
     return out, depth, feat
 
 
+def ffn_fused(x, w1, b1, w2, b2):
+    """y = x + b2 + W2 . gelu(W1 . x + b1) in one launch (transformer FFN, erf GELU).
+    x (..., 256) bf16 contiguous; w1 (F, 256) / w2 (256, F) bf16 (packed 1x1 weights are accepted as
+    (1, N, K)); b1 (F), b2 (256) fp32.  Returns fp32 of x's shape (the pre-LayerNorm sum)."""
+    w1 = w1.reshape(w1.shape[-2], w1.shape[-1])
+    w2 = w2.reshape(w2.shape[-2], w2.shape[-1])
+    F, Dm = w1.shape
+    if x.dtype != torch.bfloat16 or w1.dtype != torch.bfloat16 or w2.dtype != torch.bfloat16:
+        raise ValueError("ffn_fused: bf16 operands")
+    if not (x.is_contiguous() and w1.is_contiguous() and w2.is_contiguous()) or x.shape[-1] != Dm \
+            or tuple(w2.shape) != (Dm, F):
+        raise ValueError("ffn_fused: x (...,%d), w1 (F,%d), w2 (%d,F) contiguous" % (Dm, Dm, Dm))
+    _f32c(b1, "b1", (F,))
+    _f32c(b2, "b2", (Dm,))
+    M = x.numel() // Dm
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    with _timed("ffn_fused"):
+        N.check(N.lib().lss_ffn_fused_fwd(N.ptr(x), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(b2), M, Dm, F, N.ptr(y),
+                                          N.stream()), "lss_ffn_fused_fwd")
+    return y
+
+
 HOSTCAL_MAX_CAMS = 36
 
 

@@ -10,6 +10,7 @@ LayerNorm one row kernel).  Training / autograd runs the same parameters through
 torch ops with all heads sampled in ONE batched `grid_sample`.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -170,8 +171,15 @@ class TransformerEncoderLayer(nn.Module):
                               token_bias=self._pos_bias(pos_table))
         s1 = self._p_out.run(att, dt, residual=src, out_f32=True)
         x1 = ops.layernorm(s1, self.norm1.weight.detach(), self.norm1.bias.detach(), self.norm1.eps, tdt)
-        ff = self._p_l1.run(x1, dt, act=ops.ACT_GELU)
-        s2 = self._p_l2.run(ff, dt, residual=x1, out_f32=True)
+        d_ff, d_model = self.linear1.weight.shape
+        if dt == ops.DT_BF16 and d_model == 256 and d_ff % 64 == 0 and d_ff <= 1024 \
+                and not os.environ.get("LSS_NO_FFN_FUSED"):
+            # linear1 + GELU + linear2 + residual in one launch: the (tokens, d_ff) hidden never reaches HBM
+            (w1, b1), (w2, b2) = self._p_l1.get(dt), self._p_l2.get(dt)
+            s2 = ops.ffn_fused(x1, w1, b1, w2, b2)
+        else:
+            ff = self._p_l1.run(x1, dt, act=ops.ACT_GELU)
+            s2 = self._p_l2.run(ff, dt, residual=x1, out_f32=True)
         return ops.layernorm(s2, self.norm2.weight.detach(), self.norm2.bias.detach(), self.norm2.eps, tdt)
 
     def forward(self, src, pos, reference_points):

@@ -224,6 +224,34 @@ def test_head_major_linear_output():
     assert torch.equal(yh.permute(0, 2, 1, 3).reshape(2, 9, 14, 256), y)
 
 
+@pytest.mark.parametrize("shape,F", [((2, 9, 14), 1024), ((1, 23, 31), 256), ((3, 50, 50), 1024)])
+def test_ffn_fused_vs_two_launches_and_torch(shape, F):
+    """linear1 + GELU + linear2 + residual in one launch (ref: src/transformer_modules.py:170-172, 208):
+    same bf16 rounding points as the two-GEMM path -> agreement with it up to fp32 summation order (a hidden value
+    whose fp32 sums straddle a bf16 rounding boundary may flip by one bf16 ulp); bf16-level agreement with an fp32
+    torch evaluation.  Token counts that are not a multiple of the 128-token tile."""
+    g = torch.Generator().manual_seed(F + shape[1])
+    x = torch.randn(*shape, 256, generator=g).bfloat16().cuda()
+    w1 = (torch.randn(F, 256, 1, 1, generator=g) / 16).cuda()
+    b1 = torch.randn(F, generator=g).cuda()
+    w2 = (torch.randn(256, F, 1, 1, generator=g) / (F ** 0.5)).cuda()
+    b2 = torch.randn(256, generator=g).cuda()
+    p1, p2 = ops.pack_conv_weight(w1, ops.DT_BF16), ops.pack_conv_weight(w2, ops.DT_BF16)
+    y = ops.ffn_fused(x, p1, b1, p2, b2)
+    assert y.shape == x.shape and y.dtype == torch.float32
+    ff = ops.conv2d_nhwc(x, p1, (1, 1), 1, 0, None, b1, None, ops.ACT_GELU)
+    y2 = ops.conv2d_nhwc(ff, p2, (1, 1), 1, 0, None, b2, x, False, out_f32=True)
+    assert rel(y, y2)[0] <= 1e-3 and rel(y, y2)[1] <= 2e-5, rel(y, y2)  # max: one flipped bf16 hidden value
+    xf = x.float()
+    hid = torch.nn.functional.gelu(xf @ p1[0].float().t() + b1)
+    want = xf + hid.bfloat16().float() @ p2[0].float().t() + b2
+    assert rel(y, want)[0] <= 1e-3 and rel(y, want)[1] <= 5e-5, rel(y, want)
+    with pytest.raises(ValueError):
+        ops.ffn_fused(x.float(), p1, b1, p2, b2)
+    with pytest.raises(ValueError):
+        ops.ffn_fused(x, p1, b1, p2[:, :, :-64].contiguous(), b2)
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_bev_transformer_native(golden, prec):
     g = golden("g11_bev_transformer")
