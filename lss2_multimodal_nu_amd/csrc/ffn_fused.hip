@@ -57,7 +57,7 @@ __device__ __forceinline__ void lds_barrier() {
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7), as in linear_mfma.hip's GELU epilogue
 __device__ __forceinline__ float fast_erf(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));  // v_rcp_f32 (1 ulp); __frcp_rn is a 12-instruction IEEE division
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
