@@ -439,9 +439,12 @@ int lss_lift_splat_forward(const float* frustum, const float* inv_post_rots, con
  * leaves the CU): y = x + b2 + W2 . gelu(W1 . x + b1), erf GELU.
  * ref: src/transformer_modules.py:170-172 (linear1 / activation / linear2) + the residual add of :208.
  * x (M, d_model) bf16, w1 (d_ff, d_model) bf16, b1 (d_ff) fp32, w2 (d_model, d_ff) bf16, b2 (d_model) fp32,
- * y (M, d_model) fp32 (the pre-LayerNorm sum).  d_model = 256, d_ff a multiple of 64, <= 1024. */
+ * y (M, d_model) fp32 (the pre-LayerNorm sum).  d_model = 256, d_ff a multiple of 64, <= 1024.
+ * With ln_gamma / ln_beta (d_model, fp32) the layer's second LayerNorm (:208 `norm2`) runs in the epilogue:
+ * y_ln (M, d_model) bf16 = LN(y) * gamma + beta is written instead and y may be NULL. */
 int lss_ffn_fused_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
-                      long long M, int d_model, int d_ff, float* y, void* stream);
+                      long long M, int d_model, int d_ff, float* y, const float* ln_gamma, const float* ln_beta,
+                      float ln_eps, void* y_ln, void* stream);
 
 /* Host-calibration forms: the four per-camera arrays arrive as ONE HOST buffer of B*N*24 floats,
  * [inv_post_rots (B*N*9) | combine (B*N*9) | post_trans (B*N*3) | trans (B*N*3)], are read during the call

@@ -41,8 +41,13 @@ struct FfnArgs {
   const float* b1;           // (F)
   const unsigned short* w2;  // (256, F) bf16
   const float* b2;           // (256)
-  float* y;                  // (M, 256) fp32
+  float* y;                  // (M, 256) fp32, or null with the LayerNorm tail
   int M, F;
+  // optional LayerNorm tail (ref: src/transformer_modules.py:208 norm2): y_ln = LN(y) * gamma + beta, bf16
+  const float* ln_g;
+  const float* ln_b;
+  float ln_eps;
+  unsigned short* y_ln;
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -199,9 +204,34 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnArgs a) {
         v[2 * k] += lss_bf2f((unsigned short)(ru[k] & 0xffff));
         v[2 * k + 1] += lss_bf2f((unsigned short)(ru[k] >> 16));
       }
-      float* yo = a.y + (size_t)m * D + c8 * 8;
-      *reinterpret_cast<f32x4*>(yo) = (f32x4){v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(yo + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+      if (a.ln_g == nullptr) {
+        float* yo = a.y + (size_t)m * D + c8 * 8;
+        *reinterpret_cast<f32x4*>(yo) = (f32x4){v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(yo + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+      } else {
+        // the 32 lanes of a half-wave hold one token row: two-pass mean / variance in fp32, as layernorm_kernel
+        float sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = sum * (1.f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          v[k] -= mean;
+          sq = fmaf(v[k], v[k], sq);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        const float inv = rsqrtf(sq * (1.f / D) + a.ln_eps);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln_g + c8 * 8), g1 = *reinterpret_cast<const f32x4*>(a.ln_g + c8 * 8 + 4);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(a.ln_b + c8 * 8), t1 = *reinterpret_cast<const f32x4*>(a.ln_b + c8 * 8 + 4);
+        uint4 ov;
+        ov.x = lss_pack_bf2(v[0] * inv * g0[0] + t0[0], v[1] * inv * g0[1] + t0[1]);
+        ov.y = lss_pack_bf2(v[2] * inv * g0[2] + t0[2], v[3] * inv * g0[3] + t0[3]);
+        ov.z = lss_pack_bf2(v[4] * inv * g1[0] + t1[0], v[5] * inv * g1[1] + t1[1]);
+        ov.w = lss_pack_bf2(v[6] * inv * g1[2] + t1[2], v[7] * inv * g1[3] + t1[3]);
+        *reinterpret_cast<uint4*>(a.y_ln + (size_t)m * D + c8 * 8) = ov;
+      }
     }
   }
 }
@@ -209,12 +239,20 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnArgs a) {
 }  // namespace
 
 extern "C" int lss_ffn_fused_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
-                                 long long M, int d_model, int d_ff, float* y, void* stream) {
-  LSS_CHECK_PTR(x); LSS_CHECK_PTR(w1); LSS_CHECK_PTR(b1); LSS_CHECK_PTR(w2); LSS_CHECK_PTR(b2); LSS_CHECK_PTR(y);
+                                 long long M, int d_model, int d_ff, float* y, const float* ln_gamma,
+                                 const float* ln_beta, float ln_eps, void* y_ln, void* stream) {
+  LSS_CHECK_PTR(x); LSS_CHECK_PTR(w1); LSS_CHECK_PTR(b1); LSS_CHECK_PTR(w2); LSS_CHECK_PTR(b2);
+  const bool ln = ln_gamma != nullptr;
+  if (ln) {
+    LSS_CHECK_PTR(ln_beta); LSS_CHECK_PTR(y_ln);
+  } else {
+    LSS_CHECK_PTR(y);
+  }
   if (M <= 0 || M >= (1LL << 31) - BM) return LSS_E_SHAPE;
   if (d_model != D || d_ff <= 0 || d_ff % HC != 0 || d_ff > FMAX) return LSS_E_SHAPE;
   if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2) |
-        reinterpret_cast<uintptr_t>(y)) & 15) != 0)
+        reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y_ln) | reinterpret_cast<uintptr_t>(ln_gamma) |
+        reinterpret_cast<uintptr_t>(ln_beta)) & 15) != 0)
     return LSS_E_ALIGN;
   static bool attr_set = false;
   if (!attr_set) {
@@ -232,6 +270,10 @@ extern "C" int lss_ffn_fused_fwd(const void* x, const void* w1, const float* b1,
   a.y = y;
   a.M = (int)M;
   a.F = d_ff;
+  a.ln_g = ln_gamma;
+  a.ln_b = ln_beta;
+  a.ln_eps = ln_eps;
+  a.y_ln = reinterpret_cast<unsigned short*>(y_ln);
   hipLaunchKernelGGL(ffn_fused_kernel, dim3(lss_cdiv(M, BM)), dim3(512), SMEM_BYTES, lss_stream(stream), a);
   return lss_launch_status();
 }

@@ -321,10 +321,11 @@ def lift_splat_forward(frustum, inv_post_rots, post_trans, combine, trans, dx, b
     return out, depth, feat
 
 
-def ffn_fused(x, w1, b1, w2, b2):
+def ffn_fused(x, w1, b1, w2, b2, ln=None):
     """y = x + b2 + W2 . gelu(W1 . x + b1) in one launch (transformer FFN, erf GELU).
     x (..., 256) bf16 contiguous; w1 (F, 256) / w2 (256, F) bf16 (packed 1x1 weights are accepted as
-    (1, N, K)); b1 (F), b2 (256) fp32.  Returns fp32 of x's shape (the pre-LayerNorm sum)."""
+    (1, N, K)); b1 (F), b2 (256) fp32.  Returns fp32 of x's shape (the pre-LayerNorm sum), or - with
+    ln = (gamma, beta, eps) - LayerNorm(y) * gamma + beta in bf16, normalised in the kernel's epilogue."""
     w1 = w1.reshape(w1.shape[-2], w1.shape[-1])
     w2 = w2.reshape(w2.shape[-2], w2.shape[-1])
     F, Dm = w1.shape
@@ -336,11 +337,20 @@ def ffn_fused(x, w1, b1, w2, b2):
     _f32c(b1, "b1", (F,))
     _f32c(b2, "b2", (Dm,))
     M = x.numel() // Dm
-    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    gamma = beta = y = y_ln = None
+    eps = 0.0
+    if ln is None:
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    else:
+        gamma, beta, eps = ln
+        _f32c(gamma, "ln.gamma", (Dm,))
+        _f32c(beta, "ln.beta", (Dm,))
+        y_ln = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     with _timed("ffn_fused"):
         N.check(N.lib().lss_ffn_fused_fwd(N.ptr(x), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(b2), M, Dm, F, N.ptr(y),
-                                          N.stream()), "lss_ffn_fused_fwd")
-    return y
+                                          N.ptr(gamma), N.ptr(beta), float(eps), N.ptr(y_ln), N.stream()),
+                "lss_ffn_fused_fwd")
+    return y if ln is None else y_ln
 
 
 HOSTCAL_MAX_CAMS = 36

@@ -174,8 +174,12 @@ class TransformerEncoderLayer(nn.Module):
         d_ff, d_model = self.linear1.weight.shape
         if dt == ops.DT_BF16 and d_model == 256 and d_ff % 64 == 0 and d_ff <= 1024 \
                 and not os.environ.get("LSS_NO_FFN_FUSED"):
-            # linear1 + GELU + linear2 + residual in one launch: the (tokens, d_ff) hidden never reaches HBM
+            # linear1 + GELU + linear2 + residual (+ norm2) in one launch: neither the (tokens, d_ff) hidden nor
+            # the fp32 pre-norm sum reaches HBM
             (w1, b1), (w2, b2) = self._p_l1.get(dt), self._p_l2.get(dt)
+            if tdt == torch.bfloat16:
+                return ops.ffn_fused(x1, w1, b1, w2, b2, ln=(self.norm2.weight.detach(), self.norm2.bias.detach(),
+                                                             self.norm2.eps))
             s2 = ops.ffn_fused(x1, w1, b1, w2, b2)
         else:
             ff = self._p_l1.run(x1, dt, act=ops.ACT_GELU)

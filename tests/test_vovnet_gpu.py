@@ -246,6 +246,12 @@ def test_ffn_fused_vs_two_launches_and_torch(shape, F):
     hid = torch.nn.functional.gelu(xf @ p1[0].float().t() + b1)
     want = xf + hid.bfloat16().float() @ p2[0].float().t() + b2
     assert rel(y, want)[0] <= 1e-3 and rel(y, want)[1] <= 5e-5, rel(y, want)
+    # LayerNorm tail (norm2 in the epilogue) == layernorm kernel on the fp32 sum
+    gam, bet = (torch.rand(256, generator=g) + 0.5).cuda(), torch.randn(256, generator=g).cuda()
+    yl = ops.ffn_fused(x, p1, b1, p2, b2, ln=(gam, bet, 1e-5))
+    yl2 = ops.layernorm(y, gam, bet, 1e-5, torch.bfloat16)
+    assert yl.dtype == torch.bfloat16 and yl.shape == x.shape
+    assert rel(yl, yl2)[0] <= 8e-3 and rel(yl, yl2)[1] <= 1e-3, rel(yl, yl2)  # one bf16 ulp where the sums round apart
     with pytest.raises(ValueError):
         ops.ffn_fused(x.float(), p1, b1, p2, b2)
     with pytest.raises(ValueError):
