@@ -446,6 +446,14 @@ int lss_ffn_fused_fwd(const void* x, const void* w1, const float* b1, const void
                       long long M, int d_model, int d_ff, float* y, const float* ln_gamma, const float* ln_beta,
                       float ln_eps, void* y_ln, void* stream);
 
+/* A d_model -> d_model linear layer whose epilogue sees whole token rows: y = x . W^T + bias + residual (fp32), or -
+ * with ln_gamma / ln_beta - y_ln = LayerNorm(y) * gamma + beta (bf16) with y never written.
+ * ref: src/transformer_modules.py:155-156 (DeformableAttention.output_proj) + :204 (`src + dropout1(.)`, norm1).
+ * x, residual (M, 256) bf16; w (256, 256) bf16 row-major [out][in]; bias (256) fp32. */
+int lss_linear_res_ln_fwd(const void* x, const void* w, const float* bias, const void* residual, long long M,
+                          int d_model, float* y, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                          void* y_ln, void* stream);
+
 /* Host-calibration forms: the four per-camera arrays arrive as ONE HOST buffer of B*N*24 floats,
  * [inv_post_rots (B*N*9) | combine (B*N*9) | post_trans (B*N*3) | trans (B*N*3)], are read during the call
  * and travel inside the kernel arguments (B*N <= 36): no H2D copy, no staging buffer, one launch boundary

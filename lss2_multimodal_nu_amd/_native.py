@@ -34,6 +34,7 @@ SIGNATURES = {
     "lss_deform_attn_fwd": (_i, [_vp, _i] + [_vp] * 4 + [_i] * 7 + [_vp, _vp]),
     "lss_layernorm_fwd": (_i, [_vp, _i, _vp, _vp, ctypes.c_longlong, _i, ctypes.c_float, _vp, _i, _vp]),
     "lss_depthnet_voxels_fwd": (_i, [_vp] * 10 + [_i] * 10 + [_vp] * 5),
+    "lss_linear_res_ln_fwd": (_i, [_vp] * 4 + [ctypes.c_longlong, _i, _vp, _vp, _vp, ctypes.c_float, _vp, _vp]),
     "lss_ffn_fused_fwd": (_i, [_vp] * 5 + [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, ctypes.c_float, _vp, _vp]),
     "lss_depthnet_voxels_hostcal_fwd": (_i, [_vp] * 7 + [_i] * 10 + [_vp] * 5),
     "lss_lift_splat_forward_hostcal": (_i, [_vp] * 7 + [_i] * 10 + [_vp] * 8 + [_i, _vp]),

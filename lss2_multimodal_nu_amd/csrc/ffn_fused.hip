@@ -34,6 +34,8 @@ constexpr int SMEM_BYTES = OFF_B1 + FMAX * 4;  // 148 KiB
 constexpr int OLD = D + 4;                     // fp32 row of the staged output tile
 static_assert(BM * OLD * 4 <= OFF_B1, "the output tile is staged over the (finished) weight buffers");
 static_assert(SMEM_BYTES <= 160 * 1024, "one workgroup per CU");
+static_assert(OFF_W1 == 0 && OFF_W2 == 2 * W1_BYTES && W1_BYTES == W2_BYTES && (D / HC) * W2_BYTES <= OFF_H,
+              "PROJ mode lays its four weight chunks over the W1 + W2 buffers");
 
 struct FfnArgs {
   const unsigned short* x;   // (M, 256) bf16
@@ -42,6 +44,7 @@ struct FfnArgs {
   const unsigned short* w2;  // (256, F) bf16
   const float* b2;           // (256)
   float* y;                  // (M, 256) fp32, or null with the LayerNorm tail
+  const unsigned short* res; // (M, 256) bf16 residual rows added in the epilogue (the FFN: x itself)
   int M, F;
   // optional LayerNorm tail (ref: src/transformer_modules.py:208 norm2): y_ln = LN(y) * gamma + beta, bf16
   const float* ln_g;
@@ -72,6 +75,10 @@ __device__ __forceinline__ float fast_erf(float x) {
 }
 __device__ __forceinline__ float gelu(float v) { return 0.5f * v * (1.f + fast_erf(v * 0.70710678118654752f)); }
 
+// PROJ = false: the feed-forward block.  PROJ = true: one linear layer with the same register-resident rows,
+// y = x . W2^T + b2 + res (W2 (256, F) with F = the layer's input width = 256: chunk c multiplies x's columns
+// 64c .. 64c+63 straight from the registers - no GEMM1, no H tile), same epilogue (residual, optional LayerNorm).
+template <bool PROJ>
 __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -90,7 +97,8 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnArgs a) {
   }
   // b1 -> LDS (read back 4 floats at a time in the GELU epilogue)
   float* b1s = reinterpret_cast<float*>(smem + OFF_B1);
-  for (int i = tid; i < a.F; i += 512) b1s[i] = a.b1[i];
+  if (!PROJ)
+    for (int i = tid; i < a.F; i += 512) b1s[i] = a.b1[i];
 
   // weight DMA: 32 + 32 blocks of 1 KiB per chunk, 4 + 4 per wave.  Lane l of a block lands at byte
   // l*16: W1 block = 2 rows (row = 2*blk + (l >> 5), physical piece l & 31), W2 block = 8 rows
@@ -105,9 +113,11 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnArgs a) {
     w2o[i] = row2 * a.F + (((lane & 7) ^ ((row2 >> 1) & 7)) << 3);
   }
   auto issue = [&](int j, int buf) {
+    if (!PROJ) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      glds16(a.w1 + (size_t)j * HC * D + w1o[i], smem + OFF_W1 + buf * W1_BYTES + (wave * 4 + i) * 1024);
+      for (int i = 0; i < 4; ++i)
+        glds16(a.w1 + (size_t)j * HC * D + w1o[i], smem + OFF_W1 + buf * W1_BYTES + (wave * 4 + i) * 1024);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       glds16(a.w2 + (size_t)j * HC + w2o[i], smem + OFF_W2 + buf * W2_BYTES + (wave * 4 + i) * 1024);
@@ -133,39 +143,65 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnArgs a) {
   }
   unsigned char* hbuf = smem + OFF_H;
 
-  issue(0, 0);
+  if (PROJ) {
+    // the whole 128 KiB weight matrix fits the (contiguous) W1 + W2 buffer area: all four K chunks are
+    // requested at once and the loop below runs without further waits
+#pragma unroll
+    for (int c = 0; c < D / HC; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        glds16(a.w2 + (size_t)c * HC + w2o[i], smem + c * W2_BYTES + (wave * 4 + i) * 1024);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+  } else {
+    issue(0, 0);
+  }
   for (int j = 0; j < nchunks; ++j) {
     const int buf = j & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();  // (a): chunk j's weights are in LDS; every wave is done with chunk j-1
-    if (j + 1 < nchunks) issue(j + 1, buf ^ 1);
+    if (!PROJ) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier();  // (a): chunk j's weights are in LDS; every wave is done with chunk j-1
+      if (j + 1 < nchunks) issue(j + 1, buf ^ 1);
+    }
 
-    // GEMM1: Ht[hidden cg*32.., tokens rg*32..] over k = 256
-    const unsigned char* w1b = smem + OFF_W1 + buf * W1_BYTES + a1off;
-    f32x16 acc1;
+    if (!PROJ) {
+      // GEMM1: Ht[hidden cg*32.., tokens rg*32..] over k = 256
+      const unsigned char* w1b = smem + OFF_W1 + buf * W1_BYTES + a1off;
+      f32x16 acc1;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < D / 16; ++ks) {
-      const bf16x8 wa = *reinterpret_cast<const bf16x8*>(w1b + (((2 * ks + h) ^ a1x) << 4));
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xf[ks], acc1, 0, 0, 0);
+      for (int ks = 0; ks < D / 16; ++ks) {
+        const bf16x8 wa = *reinterpret_cast<const bf16x8*>(w1b + (((2 * ks + h) ^ a1x) << 4));
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xf[ks], acc1, 0, 0, 0);
+      }
+      // D[row = (i&3) + 8*(i>>2) + 4*h][col = r]: hidden units 8g + 4h + {0..3} of token r, g = i >> 2
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + j * HC + cg * 32 + 8 * g + 4 * h);
+        uint2 pk;
+        pk.x = lss_pack_bf2(gelu(acc1[4 * g] + bb[0]), gelu(acc1[4 * g + 1] + bb[1]));
+        pk.y = lss_pack_bf2(gelu(acc1[4 * g + 2] + bb[2]), gelu(acc1[4 * g + 3] + bb[3]));
+        *reinterpret_cast<uint2*>(hbuf + hrow + (((cg * 4 + g) ^ hx) << 4) + h * 8) = pk;
+      }
+      lds_barrier();  // (b): H_j complete
     }
-    // D[row = (i&3) + 8*(i>>2) + 4*h][col = r]: hidden units 8g + 4h + {0..3} of token r, g = i >> 2
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + j * HC + cg * 32 + 8 * g + 4 * h);
-      uint2 pk;
-      pk.x = lss_pack_bf2(gelu(acc1[4 * g] + bb[0]), gelu(acc1[4 * g + 1] + bb[1]));
-      pk.y = lss_pack_bf2(gelu(acc1[4 * g + 2] + bb[2]), gelu(acc1[4 * g + 3] + bb[3]));
-      *reinterpret_cast<uint2*>(hbuf + hrow + (((cg * 4 + g) ^ hx) << 4) + h * 8) = pk;
-    }
-    lds_barrier();  // (b): H_j complete
 
     // GEMM2: Y[tokens rg*32.., n cg*128..] += H_j . W2_j^T over k = 64
-    const unsigned char* w2b = smem + OFF_W2 + buf * W2_BYTES;
+    const unsigned char* w2b = PROJ ? smem + j * W2_BYTES : smem + OFF_W2 + buf * W2_BYTES;
 #pragma unroll
     for (int s = 0; s < HC / 16; ++s) {
-      const bf16x8 ha = *reinterpret_cast<const bf16x8*>(hbuf + hrow + (((2 * s + h) ^ hx) << 4));
+      bf16x8 ha;
+      if (PROJ) {
+        // columns 64j + 16s .. of the token row: register set 4j + s (j is a run-time index of a fully
+        // register-resident array: select with compares, the chunk loop has at most 4 trips)
+        ha = xf[s];
+#pragma unroll
+        for (int q = 1; q < D / HC; ++q)
+          if (j == q) ha = xf[4 * q + s];
+      } else {
+        ha = *reinterpret_cast<const bf16x8*>(hbuf + hrow + (((2 * s + h) ^ hx) << 4));
+      }
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
         const bf16x8 wb = *reinterpret_cast<const bf16x8*>(w2b + b2off[ct] + (((2 * s + h) ^ b2x[ct]) << 4));
@@ -175,6 +211,15 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnArgs a) {
   }
 
   // epilogue: (acc + b2) -> fp32 tile in LDS -> 8 consecutive channels per thread + residual x
+  // residual pieces of this thread's 8 passes: requested now, so the loads fly during the staging (a load per
+  // pass inside the loop below exposed one global round trip per pass: 8 x ~1.5 us per workgroup)
+  uint4 rres[BM / 16];
+#pragma unroll
+  for (int q = 0; q < BM / 16; ++q) {
+    const int m = m0 + (tid >> 5) + q * 16;
+    rres[q] = make_uint4(0, 0, 0, 0);
+    if (m < a.M) rres[q] = *reinterpret_cast<const uint4*>(a.res + (size_t)m * D + (tid & 31) * 8);
+  }
   lds_barrier();  // every wave is done reading the last chunk's buffers
   float* otile = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -196,7 +241,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnArgs a) {
       if (m >= a.M) continue;
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(otile + row * OLD + c8 * 8);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(otile + row * OLD + c8 * 8 + 4);
-      const uint4 rx = *reinterpret_cast<const uint4*>(a.x + (size_t)m * D + c8 * 8);
+      const uint4 rx = rres[q];
       const unsigned int ru[4] = {rx.x, rx.y, rx.z, rx.w};
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
@@ -238,10 +283,13 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnArgs a) {
 
 }  // namespace
 
-extern "C" int lss_ffn_fused_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
-                                 long long M, int d_model, int d_ff, float* y, const float* ln_gamma,
-                                 const float* ln_beta, float ln_eps, void* y_ln, void* stream) {
-  LSS_CHECK_PTR(x); LSS_CHECK_PTR(w1); LSS_CHECK_PTR(b1); LSS_CHECK_PTR(w2); LSS_CHECK_PTR(b2);
+static int ffn_launch(bool proj, const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                      const void* res, long long M, int d_model, int d_ff, float* y, const float* ln_gamma,
+                      const float* ln_beta, float ln_eps, void* y_ln, void* stream) {
+  LSS_CHECK_PTR(x); LSS_CHECK_PTR(w2); LSS_CHECK_PTR(b2); LSS_CHECK_PTR(res);
+  if (!proj) {
+    LSS_CHECK_PTR(w1); LSS_CHECK_PTR(b1);
+  }
   const bool ln = ln_gamma != nullptr;
   if (ln) {
     LSS_CHECK_PTR(ln_beta); LSS_CHECK_PTR(y_ln);
@@ -249,17 +297,18 @@ extern "C" int lss_ffn_fused_fwd(const void* x, const void* w1, const float* b1,
     LSS_CHECK_PTR(y);
   }
   if (M <= 0 || M >= (1LL << 31) - BM) return LSS_E_SHAPE;
-  if (d_model != D || d_ff <= 0 || d_ff % HC != 0 || d_ff > FMAX) return LSS_E_SHAPE;
+  if (d_model != D || d_ff <= 0 || d_ff % HC != 0 || d_ff > FMAX || (proj && d_ff != D)) return LSS_E_SHAPE;
   if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2) |
         reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y_ln) | reinterpret_cast<uintptr_t>(ln_gamma) |
-        reinterpret_cast<uintptr_t>(ln_beta)) & 15) != 0)
+        reinterpret_cast<uintptr_t>(ln_beta) | reinterpret_cast<uintptr_t>(res)) & 15) != 0)
     return LSS_E_ALIGN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_fused_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+  static bool attr_set[2] = {false, false};
+  const void* fn = proj ? reinterpret_cast<const void*>(ffn_fused_kernel<true>)
+                        : reinterpret_cast<const void*>(ffn_fused_kernel<false>);
+  if (!attr_set[proj]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set[proj] = true;
   }
   FfnArgs a;
   a.x = reinterpret_cast<const unsigned short*>(x);
@@ -268,12 +317,31 @@ extern "C" int lss_ffn_fused_fwd(const void* x, const void* w1, const float* b1,
   a.w2 = reinterpret_cast<const unsigned short*>(w2);
   a.b2 = b2;
   a.y = y;
+  a.res = reinterpret_cast<const unsigned short*>(res);
   a.M = (int)M;
   a.F = d_ff;
   a.ln_g = ln_gamma;
   a.ln_b = ln_beta;
   a.ln_eps = ln_eps;
   a.y_ln = reinterpret_cast<unsigned short*>(y_ln);
-  hipLaunchKernelGGL(ffn_fused_kernel, dim3(lss_cdiv(M, BM)), dim3(512), SMEM_BYTES, lss_stream(stream), a);
+  if (proj)
+    hipLaunchKernelGGL(ffn_fused_kernel<true>, dim3(lss_cdiv(M, BM)), dim3(512), SMEM_BYTES, lss_stream(stream), a);
+  else
+    hipLaunchKernelGGL(ffn_fused_kernel<false>, dim3(lss_cdiv(M, BM)), dim3(512), SMEM_BYTES, lss_stream(stream), a);
   return lss_launch_status();
+}
+
+extern "C" int lss_ffn_fused_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                                 long long M, int d_model, int d_ff, float* y, const float* ln_gamma,
+                                 const float* ln_beta, float ln_eps, void* y_ln, void* stream) {
+  return ffn_launch(false, x, w1, b1, w2, b2, x, M, d_model, d_ff, y, ln_gamma, ln_beta, ln_eps, y_ln, stream);
+}
+
+// y = x . W^T + bias + residual (fp32), or LayerNorm of it (bf16): a 256 -> 256 linear layer whose epilogue
+// sees whole token rows.  ref: src/transformer_modules.py:155-156 (output_proj) + :204 (`src + dropout1(.)`, norm1).
+extern "C" int lss_linear_res_ln_fwd(const void* x, const void* w, const float* bias, const void* residual,
+                                     long long M, int d_model, float* y, const float* ln_gamma,
+                                     const float* ln_beta, float ln_eps, void* y_ln, void* stream) {
+  return ffn_launch(true, x, nullptr, nullptr, w, bias, residual, M, d_model, d_model, y, ln_gamma, ln_beta, ln_eps,
+                    y_ln, stream);
 }

@@ -353,6 +353,35 @@ def ffn_fused(x, w1, b1, w2, b2, ln=None):
     return y if ln is None else y_ln
 
 
+def linear_res_ln(x, w, bias, residual, ln=None):
+    """x . W^T + bias + residual for a 256 -> 256 layer, fp32 - or, with ln = (gamma, beta, eps), its LayerNorm
+    in bf16 without the fp32 sum ever being written.  x, residual (..., 256) bf16; w (256, 256) bf16 (packed
+    1x1 weights (1, N, K) accepted); bias (256) fp32."""
+    w = w.reshape(w.shape[-2], w.shape[-1])
+    Dm = x.shape[-1]
+    if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or residual.dtype != torch.bfloat16:
+        raise ValueError("linear_res_ln: bf16 operands")
+    if not (x.is_contiguous() and w.is_contiguous() and residual.is_contiguous()) or tuple(w.shape) != (Dm, Dm) \
+            or residual.shape != x.shape:
+        raise ValueError("linear_res_ln: x, residual (...,%d) and w (%d,%d) contiguous" % (Dm, Dm, Dm))
+    _f32c(bias, "bias", (Dm,))
+    M = x.numel() // Dm
+    gamma = beta = y = y_ln = None
+    eps = 0.0
+    if ln is None:
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    else:
+        gamma, beta, eps = ln
+        _f32c(gamma, "ln.gamma", (Dm,))
+        _f32c(beta, "ln.beta", (Dm,))
+        y_ln = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    with _timed("linear_res_ln"):
+        N.check(N.lib().lss_linear_res_ln_fwd(N.ptr(x), N.ptr(w), N.ptr(bias), N.ptr(residual), M, Dm, N.ptr(y),
+                                              N.ptr(gamma), N.ptr(beta), float(eps), N.ptr(y_ln), N.stream()),
+                "lss_linear_res_ln_fwd")
+    return y if ln is None else y_ln
+
+
 HOSTCAL_MAX_CAMS = 36
 
 

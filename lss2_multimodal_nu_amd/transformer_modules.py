@@ -169,8 +169,14 @@ class TransformerEncoderLayer(nn.Module):
         val = self._p_val.run(src, dt, head_major=(dt == ops.DT_BF16))  # gather-friendly layout from the GEMM
         att = ops.deform_attn(val, ol, ref_x, ref_y, self.self_attn.n_heads, self.self_attn.n_points,
                               token_bias=self._pos_bias(pos_table))
-        s1 = self._p_out.run(att, dt, residual=src, out_f32=True)
-        x1 = ops.layernorm(s1, self.norm1.weight.detach(), self.norm1.bias.detach(), self.norm1.eps, tdt)
+        if dt == ops.DT_BF16 and tdt == torch.bfloat16 and src.shape[-1] == 256 and not os.environ.get("LSS_NO_FFN_FUSED"):
+            # output_proj + residual + norm1 in one launch (whole token rows per workgroup)
+            wo, bo = self._p_out.get(dt)
+            x1 = ops.linear_res_ln(att, wo, bo, src, ln=(self.norm1.weight.detach(), self.norm1.bias.detach(),
+                                                         self.norm1.eps))
+        else:
+            s1 = self._p_out.run(att, dt, residual=src, out_f32=True)
+            x1 = ops.layernorm(s1, self.norm1.weight.detach(), self.norm1.bias.detach(), self.norm1.eps, tdt)
         d_ff, d_model = self.linear1.weight.shape
         if dt == ops.DT_BF16 and d_model == 256 and d_ff % 64 == 0 and d_ff <= 1024 \
                 and not os.environ.get("LSS_NO_FFN_FUSED"):

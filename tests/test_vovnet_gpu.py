@@ -258,6 +258,28 @@ def test_ffn_fused_vs_two_launches_and_torch(shape, F):
         ops.ffn_fused(x, p1, b1, p2[:, :, :-64].contiguous(), b2)
 
 
+def test_linear_res_ln_vs_gemm_and_layernorm_kernels():
+    """output_proj + residual + norm1 in one launch (ref: src/transformer_modules.py:155-156, 204) against the
+    GEMM kernel + the layernorm kernel, and against torch in fp32."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(2, 37, 41, 256, generator=g).bfloat16().cuda()
+    res = torch.randn(2, 37, 41, 256, generator=g).bfloat16().cuda()
+    w = (torch.randn(256, 256, 1, 1, generator=g) / 16).cuda()
+    b = torch.randn(256, generator=g).cuda()
+    gam, bet = (torch.rand(256, generator=g) + 0.5).cuda(), torch.randn(256, generator=g).cuda()
+    wp = ops.pack_conv_weight(w, ops.DT_BF16)
+    y = ops.linear_res_ln(x, wp, b, res)
+    y2 = ops.conv2d_nhwc(x, wp, (1, 1), 1, 0, None, b, res, False, out_f32=True)
+    assert y.dtype == torch.float32 and rel(y, y2)[0] <= 2e-6, rel(y, y2)
+    want = x.float() @ wp[0].float().t() + b + res.float()
+    assert rel(y, want)[0] <= 1e-5
+    yl = ops.linear_res_ln(x, wp, b, res, ln=(gam, bet, 1e-5))
+    yl2 = ops.layernorm(y2, gam, bet, 1e-5, torch.bfloat16)
+    assert yl.dtype == torch.bfloat16 and rel(yl, yl2)[0] <= 8e-3 and rel(yl, yl2)[1] <= 1e-3, rel(yl, yl2)
+    with pytest.raises(ValueError):
+        ops.linear_res_ln(x, wp, b, res[:1])
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_bev_transformer_native(golden, prec):
     g = golden("g11_bev_transformer")
