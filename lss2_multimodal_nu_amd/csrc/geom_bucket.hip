@@ -13,11 +13,6 @@ struct Mat3 {
   float m[9];
 };
 
-__device__ __forceinline__ void load_mat3(const float* __restrict__ p, Mat3& a) {
-#pragma unroll
-  for (int i = 0; i < 9; ++i) a.m[i] = p[i];
-}
-
 // ((m0*p0 + m1*p1) + m2*p2), every operation rounded (no contraction in this TU)
 __device__ __forceinline__ float row_dot(const float* m, float p0, float p1, float p2) {
   float t = __fmul_rn(m[0], p0);
