@@ -291,24 +291,27 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// conv3x3_lds_kernel: 3x3 / stride 1 / pad 1, bf16 - the shape that carries 95 %
-// of BevEncode's FLOPs.  Output-stationary, LDS-tiled:
-//   * workgroup (256 threads, 2 per CU) = TH x 16 output pixels x BN output
-//     channels of one image; every wave owns 4 pixel rows x 64 channels =
-//     2 x 2 tiles of v_mfma_f32_32x32x16_bf16 (64 accumulator registers);
-//   * per 64-channel chunk of the input the (TH+2) x 18 halo'd input patch is
-//     gathered ONCE into LDS (the fused bilinear-upsample / concat gather runs
-//     here, once per element instead of once per tap) and re-used by all 9
-//     taps through shifted ds_read_b128 windows;
-//   * per (chunk, tap) step the BN x 64 weight slab streams global -> LDS by
-//     LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) into a 3-slot ring,
-//     two steps ahead of the MFMAs; the step barrier is a raw s_barrier behind a
-//     COUNTED vmcnt, so the younger slab stays in flight across it.
-// LDS images: patch positions are 144 B apart (128 B of channels + 16 B pad) and
-// patch rows are padded to a multiple of 256 B, which makes the two pixel rows of a
-// 32-row MFMA tile land on complementary bank sets (conflict-free ds_read_b128);
-// weight rows are 128 B, XOR-swizzled by ((row >> 1) & 7) on the DMA's SOURCE
-// address (the DMA destination is lane-linear) and on the read address.
+// conv_lds_kernel: the bf16 convolutions of BevEncode (3x3 / stride 1 carries 95 % of its FLOPs; the
+// stride-2 3x3 / 7x7 run as stride-1 convs over the four parity phases, MODE 2).  Output-stationary,
+// LDS-tiled:
+//   * workgroup (256 threads; 2 per CU, 3 with KC = 32) = TH x 16 output pixels x BN output channels
+//     of one image; a wave owns RT x 2 tiles of v_mfma_f32_32x32x16_bf16 (RT = 2: 4 pixel rows x 64
+//     channels, 64 accumulator registers; RT = 1 for grids that would leave CUs idle);
+//   * per KC-channel chunk (64, or 32 for the fused-gather layers) of the input the (TH+2) x 18 halo'd
+//     patch is gathered ONCE into LDS (the fused bilinear-upsample / concat gather runs here, once per
+//     element instead of once per tap; its low-res source window is itself staged by LDS-DMA, see
+//     SRC) and re-used by all taps through shifted ds_read_b128 windows;
+//   * per (chunk, tap) step the BN x KC weight slab streams global -> LDS by LDS-DMA
+//     (global_load_lds_dwordx4, no VGPR round trip) into a 3-slot ring, two steps ahead of the
+//     MFMAs; the step barrier is a raw s_barrier behind a COUNTED vmcnt, so the younger slab stays in
+//     flight across it;
+//   * KSP = 2 (512 threads): two 4-wave groups split the input channels of one tile (grids of at most
+//     256 workgroups); the epilogue stages the fp32 tile in LDS and stores 16-B pieces (write-through),
+//     optionally reducing a fused 1x1 head instead.
+// LDS images: patch positions are KC*2 + 16 B apart (the 16-B pad) and patch rows are padded to a
+// multiple of 256 B, which makes the two pixel rows of a 32-row MFMA tile land on complementary bank
+// sets (conflict-free ds_read_b128); weight rows are KC*2 B, XOR-swizzled in 16-B pieces on the DMA's
+// SOURCE address (the DMA destination is lane-linear) and on the read address.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
