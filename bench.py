@@ -59,13 +59,14 @@ def l1_bytes_per_frame(N, fH, fW, C, X, Y, Z, D, out_bytes):
 
 
 def pmc_traffic(kernel_prefix, grid=None):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json,
-    made by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes of this same
-    command); None when no such file exists.  bench.py itself cannot run the profiler."""
+    """(HBM bytes per launch, source file) from the committed rocprofv3 PMC passes
+    (profiles/*_hbm_traffic.json, made by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE
+    passes of this same command); (None, None) when no such file exists.  bench.py itself cannot run
+    the profiler."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
     if not files:
-        return None
+        return None, None
     d = json.load(open(files[-1]))
     tot, n = 0.0, 0
     for k, v in d.items():
@@ -73,7 +74,7 @@ def pmc_traffic(kernel_prefix, grid=None):
         if name.startswith(kernel_prefix) and (grid is None or g == str(grid)):
             tot += (v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
             n += v["launches"]
-    return {"bytes_per_launch": tot / n, "source": os.path.basename(files[-1])} if n else None
+    return (tot / n, os.path.basename(files[-1])) if n else (None, None)
 
 
 def main():
@@ -214,6 +215,7 @@ def main():
     splat_bytes_step = l1_bytes_step
     spl_gbs = splat_bytes_step * args.steps / (ms_spl * 1e-3) / 1e9 if ms_spl else 0.0
 
+    conv_traffic, splat_traffic = pmc_traffic("conv_"), pmc_traffic("lift_splat_fwd_kernel")
     out = {
         "metric": "BEV frames/sec (6-cam 352x128 -> 200x200x64), full hot path: CamEncode lift + splat + BevEncode",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -231,12 +233,14 @@ def main():
         "roofline": {"kernel": "conv_lds_kernel (+3 conv_direct_kernel): the 18 BevEncode launches of a step, one HIP-event "
                                "bracket around the group (per-launch brackets cost ~10 us of idle each)",
                      "bound": "mfma", "achieved": conv_tf, "peak": peak_tf, "unit": "TFLOP/s",
-                     "frac": conv_tf / peak_tf, "traffic": pmc_traffic("conv_"), "launches": n_conv * 18,
+                     "frac": conv_tf / peak_tf, "traffic": conv_traffic[0], "traffic_unit": "HBM bytes per launch (PMC)",
+                     "traffic_source": conv_traffic[1], "launches": n_conv * 18,
                      "avg_us": ms_conv * 1e3 / max(n_conv * 18, 1), "flops_per_step": conv_flops_step},
         "roofline_l1": {"kernel": "lift-splat level = points_to_voxels + depthnet_softmax + bucket_alloc + bucket_fill + "
                                   "lift_splat_fwd (5 launches, one HIP-event bracket); `traffic` is lift_splat_fwd_kernel's own",
                         "bound": "hbm", "achieved": spl_gbs, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": spl_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("lift_splat_fwd_kernel"),
+                        "unit": "GB/s", "frac": spl_gbs / HBM_PEAK_GBS, "traffic": splat_traffic[0],
+                        "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": splat_traffic[1],
                         "launches": n_spl * 5,
                         "avg_us": ms_spl * 1e3 / max(n_spl * 5, 1), "level_us": ms_spl * 1e3 / max(n_spl, 1),
                         "bytes_per_step": splat_bytes_step},
