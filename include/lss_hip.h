@@ -401,9 +401,10 @@ int lss_conv2d_s2_dual_fwd(const void* x, const void* w_s2d, const float* scale,
                            int pad, int relu, void* stream);
 
 /* 3x3/s1/p1 conv (+ fused upsample/concat gather) + scale/shift + ReLU + fused 1x1
- * head, bf16 in, NCHW fp32 out (B, head_n, H*up, W*up).  Cout must be 128.
- * replaces: src/modules.py:110-116 (up2: upsample, conv3x3, BN, ReLU, conv1x1+bias)
- *   head_w (head_n, 128) fp32, head_b (head_n) fp32 */
+ * head, bf16 in, NCHW fp32 out (B, head_n, H*up, W*up).  Cout = 128, or 64 for the plain 3x3 (up = 1, C2 = 0).
+ * replaces: src/modules.py:110-116 (up2: upsample, conv3x3, BN, ReLU, conv1x1+bias) and
+ *   src/model_vovnet_transformer.py:141-143 (seg_head: conv3x3 128->64, BN, ReLU, conv1x1)
+ *   head_w (head_n, Cout) fp32, head_b (head_n) fp32 */
 int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_packed, const float* scale,
                         const float* shift, const float* head_w, const float* head_b, float* out,
                         int B, int H, int W, int Cx, int C2, int up, int Cout, int head_n,

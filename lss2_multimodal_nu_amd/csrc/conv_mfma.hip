@@ -827,11 +827,11 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
     if (grp != 0) {
       // second K-split group: its sums were handed over above; it only keeps the barriers company
     } else if (a.head_out) {
-      // fused 1x1 head: the 16 lanes that hold the BN = 128 channels of one pixel reduce
-      // their partial dot products with shuffles; the activation itself is never stored
-      if (BN == 128) {
-        for (int e = tid; e < HROWS * 16 * 16; e += 256) {
-          const int pl = e >> 4, hc8 = e & 15;
+      // fused 1x1 head: the CG = BN / 8 lanes that hold the channels of one pixel reduce their partial
+      // dot products with shuffles; the activation itself is never stored
+      {
+        for (int e = tid; e < HROWS * 16 * CG; e += 256) {
+          const int pl = e / CG, hc8 = e % CG;
           const int oy = oy0 + half * HROWS + (pl >> 4), hx = ox0 + (pl & 15);
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + hc8 * 8);
           const f32x4 v1 = *reinterpret_cast<const f32x4*>(otile + pl * OLD + hc8 * 8 + 4);
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
 #pragma unroll
             for (int j = 0; j < 8; ++j) part = fmaf(v[j], hw[j], part);
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            for (int o = CG / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
             if (hc8 == 0 && oy < a.Ho && hx < a.Wo)
               a.head_out[(((size_t)b * a.head_n + k) * a.Ho + oy) * a.Wo + hx] = part + a.head_b[k];
           }
@@ -1210,7 +1210,8 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
   LSS_CHECK_PTR(out);
   LSS_CHECK_POS(B); LSS_CHECK_POS(H); LSS_CHECK_POS(W); LSS_CHECK_POS(Cx); LSS_CHECK_POS(up);
   LSS_CHECK_POS(head_n);
-  if (Cout != 128 || C2 < 0 || Cx % 64 != 0 || C2 % 64 != 0 || head_n > 64) return LSS_E_SHAPE;
+  if ((Cout != 128 && Cout != 64) || C2 < 0 || Cx % 64 != 0 || C2 % 64 != 0 || head_n > 64) return LSS_E_SHAPE;
+  if (Cout == 64 && (up != 1 || C2 != 0)) return LSS_E_SHAPE;  // the 64-wide tile has no fused-gather form
   if (C2 > 0 && x2 == nullptr) return LSS_E_NULL;
   ConvArgs a;
   a.stamps = conv_stamps_from_env();
@@ -1233,7 +1234,7 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
   a.ry = a.Hin > 1 ? (float)(H - 1) / (float)(a.Hin - 1) : 0.f;
   a.rx = a.Win > 1 ? (float)(W - 1) / (float)(a.Win - 1) : 0.f;
   const bool fused = (up > 1) || (C2 > 0);
-  const int tilesX = lss_cdiv(a.Wo, 16), tilesY = lss_cdiv(a.Ho, 8);
+  const int tilesX = lss_cdiv(a.Wo, 16), tilesY = lss_cdiv(a.Ho, Cout == 64 ? 16 : 8);
   dim3 g(tilesX * tilesY * B, 1);
   hipStream_t st = lss_stream(stream);
   // the fused-gather form takes the 32-channel steps (three workgroups per CU), as in launch_conv_lds
@@ -1245,6 +1246,8 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
   }
   else if (fused)
     hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
+  else if (Cout == 64)
+    hipLaunchKernelGGL((conv_lds_kernel<2, 64, 0, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
   else
     hipLaunchKernelGGL((conv_lds_kernel<2, 128, 0, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
   return lss_launch_status();

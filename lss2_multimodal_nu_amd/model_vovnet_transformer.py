@@ -150,7 +150,15 @@ class BEVEncoderTransformer(nn.Module):
         """HIP path.  x (B,H,W,C_in) NHWC in dt -> seg (B,out_C,H,W) fp32 NCHW, refined (B,H,W,256) NHWC in dt."""
         h = self._fc.run(x, dt, relu=True)
         refined = self.transformer.forward_nhwc(h, dt)
-        s = self._fs1.run(self._fs0.run(refined, dt, relu=True), dt, relu=True)
+        s = self._fs0.run(refined, dt, relu=True)
+        head = self.seg_head[6]
+        if dt == ops.DT_BF16 and self.seg_head[3].out_channels == 64 and head.out_channels <= 64:
+            # second 3x3 + BN + ReLU + the 1x1 classifier in ONE launch, NCHW fp32 out: the 64-channel
+            # activation is never stored (ref: model_vovnet_transformer.py:139-143)
+            w1, sc1, sh1 = self._fs1.get(dt)
+            hw = head.weight.detach().float().reshape(head.out_channels, -1).contiguous()
+            return ops.conv3x3_head_nchw(s, w1, sc1, sh1, hw, head.bias.detach().float().contiguous(), up=1), refined
+        s = self._fs1.run(s, dt, relu=True)
         w, _, shift = self._fs2.get(dt)
         seg = ops.conv2d_nhwc(s, w, (1, 1), 1, 0, None, shift, None, False, dt=dt, out_f32=True)
         return seg.permute(0, 3, 1, 2).contiguous(), refined

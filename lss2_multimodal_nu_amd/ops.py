@@ -888,12 +888,15 @@ def conv2d_s2_dual_nhwc(x, w_s2d, scale, shift, split, relu=True, tag="conv2d_fw
 
 def conv3x3_head_nchw(x, w_packed, scale, shift, head_w, head_b, x2=None, up=1, relu=True, tag="conv2d_fwd"):
     """3x3/s1/p1 conv (+fused upsample/concat) + scale/shift + ReLU + 1x1 head in one launch.
-    x (B,H,W,Cx) bf16 NHWC; head_w (n,128) fp32; returns (B, n, H*up, W*up) fp32 NCHW."""
+    x (B,H,W,Cx) bf16 NHWC; head_w (n,Cout) fp32, Cout = 128 (64: plain 3x3 only); returns (B, n, H*up, W*up)
+    fp32 NCHW."""
     B, H, W, Cx = x.shape
     taps, Cout, Cin = w_packed.shape
     C2 = x2.shape[3] if x2 is not None else 0
-    if x.dtype != torch.bfloat16 or not x.is_contiguous() or taps != 9 or Cin != Cx + C2 or Cout != 128:
-        raise ValueError("conv3x3_head_nchw: bf16 NHWC input, 3x3 weights with Cout == 128 required")
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or taps != 9 or Cin != Cx + C2 or Cout not in (64, 128) \
+            or (Cout == 64 and (up != 1 or C2 != 0)):
+        raise ValueError("conv3x3_head_nchw: bf16 NHWC input, 3x3 weights with Cout == 128 (or 64 without "
+                         "upsample / concat) required")
     n = head_w.shape[0]
     _f32c(head_w, "head_w", (n, Cout))
     _f32c(head_b, "head_b", (n,))

@@ -258,6 +258,23 @@ def test_ffn_fused_vs_two_launches_and_torch(shape, F):
         ops.ffn_fused(x, p1, b1, p2[:, :, :-64].contiguous(), b2)
 
 
+def test_conv3x3_head_64_wide_vs_two_launches():
+    """seg_head tail (ref: src/model_vovnet_transformer.py:141-143): 3x3 128->64 + BN + ReLU + 1x1 in one launch
+    against the conv kernel followed by the 1x1 conv (which sees the bf16-rounded activation)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 37, 45, 128, generator=g).bfloat16().cuda()
+    w = (torch.randn(64, 128, 3, 3, generator=g) / 34).cuda()
+    sc, sh = (torch.rand(64, generator=g) + 0.5).cuda(), torch.randn(64, generator=g).cuda()
+    hw, hb = (torch.randn(4, 64, generator=g) / 8).cuda(), torch.randn(4, generator=g).cuda()
+    wp = ops.pack_conv_weight(w, ops.DT_BF16)
+    y = ops.conv3x3_head_nchw(x, wp, sc, sh, hw, hb, up=1)
+    act = ops.conv2d_nhwc(x, wp, (3, 3), 1, 1, sc, sh, None, True, out_f32=True)  # fp32 activation
+    want = torch.einsum("bhwc,kc->bkhw", act, hw) + hb.view(1, -1, 1, 1)
+    assert y.shape == (2, 4, 37, 45) and rel(y, want)[0] <= 1e-5, rel(y, want)
+    with pytest.raises(ValueError):
+        ops.conv3x3_head_nchw(x, wp, sc, sh, hw, hb, up=2)
+
+
 def test_linear_res_ln_vs_gemm_and_layernorm_kernels():
     """output_proj + residual + norm1 in one launch (ref: src/transformer_modules.py:155-156, 204) against the
     GEMM kernel + the layernorm kernel, and against torch in fp32."""
