@@ -7,6 +7,8 @@
 // (conv_mfma.hip).  Activations are (B, H*W, 256) rows = NHWC; all three kernels
 // are bandwidth / gather bound: one wave per token, 4 channels per lane, 16-B or
 // 8-B accesses, no LDS.
+#include <type_traits>
+
 #include "lss_common.h"
 
 namespace {
@@ -165,24 +167,34 @@ __global__ __launch_bounds__(256) void deform_attn_kernel(
   f32x2 acc[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) acc[k] = (f32x2){0.f, 0.f};
-  // one iteration = the two points prepared by lane q of the (token, head) quad: 8 taps in
-  // flight per lane.  Not unrolled further: the compiler would hoist all 32 loads and spill.
-#pragma unroll 1
-  for (int q = 0; q < 4; ++q) {
-    const int src = (lane & ~3) | q;
+  // one step = the two points prepared by lane q of the (token, head) quad: 8 taps in flight per lane.
+  // The tap parameters come from quad lane q by DPP quad_perm broadcasts (VALU moves; as ds_bpermute
+  // shuffles they were 64 LDS operations per lane).  The scheduling barrier between the steps keeps the compiler from
+  // hoisting all 32 tap loads to the top (occupancy: this kernel lives on many waves hiding gather latency).
+  auto step = [&](auto qc) {
+    constexpr int Q = decltype(qc)::value;
+    constexpr int CTRL = Q | (Q << 2) | (Q << 4) | (Q << 6);  // quad_perm [Q, Q, Q, Q]
+    auto bi = [&](int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); };
+    auto bf = [&](float v) { return __builtin_bit_cast(float, bi(__builtin_bit_cast(int, v))); };
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const TapSet& m = half ? tb : ta;
-      const int j00 = __shfl(m.i00, src, 64), j01 = __shfl(m.i01, src, 64);
-      const int j10 = __shfl(m.i10, src, 64), j11 = __shfl(m.i11, src, 64);
-      const float u00 = __shfl(m.w00, src, 64), u01 = __shfl(m.w01, src, 64);
-      const float u10 = __shfl(m.w10, src, 64), u11 = __shfl(m.w11, src, 64);
+      const int j00 = bi(m.i00), j01 = bi(m.i01), j10 = bi(m.i10), j11 = bi(m.i11);
+      const float u00 = bf(m.w00), u01 = bf(m.w01), u10 = bf(m.w10), u11 = bf(m.w11);
       blend8(acc, vb + (size_t)j00 * pstr, u00);
       blend8(acc, vb + (size_t)j01 * pstr, u01);
       blend8(acc, vb + (size_t)j10 * pstr, u10);
       blend8(acc, vb + (size_t)j11 * pstr, u11);
     }
-  }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // each step sits behind its own opaque (always true) scalar condition: control dependence is what
+  // actually stops the tap loads of later steps from being scheduled first
+  auto gate = []() { int one; asm volatile("s_mov_b32 %0, 1" : "=s"(one)); return one != 0; };
+  if (gate()) step(std::integral_constant<int, 0>{});
+  if (gate()) step(std::integral_constant<int, 1>{});
+  if (gate()) step(std::integral_constant<int, 2>{});
+  if (gate()) step(std::integral_constant<int, 3>{});
   if (live) store8(out + row * TC + head * 32 + 8 * sub, acc);
 }
 
