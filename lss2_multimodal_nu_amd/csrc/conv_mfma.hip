@@ -92,6 +92,12 @@ struct Frag<float> {
 // vmcnt(0), which would expose the latency of the weight / patch prefetch loads
 // that are meant to stay in flight across it (cdna_hip_programming.md section 5,
 // "Pipelining across barriers").
+// x of the lane a DPP control selects (quad_perm / row_mirror / row_half_mirror: all inside a row of 16)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -845,8 +851,13 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
             float part = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) part = fmaf(v[j], hw[j], part);
-#pragma unroll
-            for (int o = CG / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            // sum over the CG lanes of the pixel on DPP row operations (no LDS round trips): lane ^ 1,
+            // lane ^ 2, then - every quad now holding its sum - the other quad of the 8 (row_half_mirror)
+            // and the other half of the 16 (row_mirror)
+            part += dpp_f32<0xB1>(part);
+            part += dpp_f32<0x4E>(part);
+            part += dpp_f32<0x141>(part);
+            if (CG == 16) part += dpp_f32<0x140>(part);
             if (hc8 == 0 && oy < a.Ho && hx < a.Wo)
               a.head_out[(((size_t)b * a.head_n + k) * a.Ho + oy) * a.Wo + hx] = part + a.head_b[k];
           }
