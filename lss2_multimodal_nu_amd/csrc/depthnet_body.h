@@ -20,6 +20,16 @@ __device__ __forceinline__ void depthnet_epilogue(const f32x4 (&acc)[NT], float*
   const int col = lane & 15, j = lane >> 4;
   // logit rows: depth bins at [0, D), context channels at [feat_row0, feat_row0 + C)
   const int NO = feat_row0 + C;
+  // biases of the logits this thread finishes below: requested now, so the loads fly during the partial
+  // stores and the barrier instead of one exposed round trip per pass of the reduce loop
+  float bias_v[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int n = (tid + i * 256) / PIX;
+    bias_v[i] = 0.f;
+    if (n < D) bias_v[i] = bias_d[n];
+    else if (n >= feat_row0 && n < NO) bias_v[i] = bias_c[n - feat_row0];
+  }
   // partial[wave][n][pix] -> LDS
   float* part = lds;  // [4][NT*16][LDS_LD]
   const int NR = NT * 16;
@@ -31,15 +41,17 @@ __device__ __forceinline__ void depthnet_epilogue(const f32x4 (&acc)[NT], float*
   __syncthreads();
   // reduce the four K quarters (fixed order -> deterministic), add bias
   float* logit = lds + 4 * NR * LDS_LD;  // [NR][LDS_LD]
-  for (int e = tid; e < NO * PIX; e += 256) {
-    const int n = e / PIX, p = e % PIX;
-    const int o = n * LDS_LD + p;
-    float v = part[o] + part[NR * LDS_LD + o];
-    v += part[2 * NR * LDS_LD + o];
-    v += part[3 * NR * LDS_LD + o];
-    if (n < D) v += bias_d[n];
-    else if (n >= feat_row0) v += bias_c[n - feat_row0];
-    logit[o] = v;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int e = tid + i * 256;
+    if (e < NO * PIX) {
+      const int n = e / PIX, p = e % PIX;
+      const int o = n * LDS_LD + p;
+      float v = part[o] + part[NR * LDS_LD + o];
+      v += part[2 * NR * LDS_LD + o];
+      v += part[3 * NR * LDS_LD + o];
+      logit[o] = v + bias_v[i];
+    }
   }
   __syncthreads();
 
