@@ -235,6 +235,15 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnArgs a) {
   lds_barrier();
   {
     const int c8 = tid & 31, row0 = tid >> 5;  // 512 threads = 16 rows x 32 channel groups per pass
+    // LayerNorm scale / shift of this thread's 8 channels: the same for every pass (loaded once, not per pass -
+    // the stores to y_ln would otherwise force a reload each time)
+    f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0, t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+    if (a.ln_g != nullptr) {
+      g0 = *reinterpret_cast<const f32x4*>(a.ln_g + c8 * 8);
+      g1 = *reinterpret_cast<const f32x4*>(a.ln_g + c8 * 8 + 4);
+      t0 = *reinterpret_cast<const f32x4*>(a.ln_b + c8 * 8);
+      t1 = *reinterpret_cast<const f32x4*>(a.ln_b + c8 * 8 + 4);
+    }
 #pragma unroll
     for (int q = 0; q < BM / 16; ++q) {
       const int row = row0 + q * 16, m = m0 + row;
@@ -268,8 +277,6 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnArgs a) {
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
         const float inv = rsqrtf(sq * (1.f / D) + a.ln_eps);
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln_g + c8 * 8), g1 = *reinterpret_cast<const f32x4*>(a.ln_g + c8 * 8 + 4);
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(a.ln_b + c8 * 8), t1 = *reinterpret_cast<const f32x4*>(a.ln_b + c8 * 8 + 4);
         uint4 ov;
         ov.x = lss_pack_bf2(v[0] * inv * g0[0] + t0[0], v[1] * inv * g0[1] + t0[1]);
         ov.y = lss_pack_bf2(v[2] * inv * g0[2] + t0[2], v[3] * inv * g0[3] + t0[3]);
