@@ -45,6 +45,20 @@ class TrunkFeatures(nn.Module):
             x = x.reshape(-1, *x.shape[2:])
         return x
 
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        """A reference checkpoint carries `encoder.trunk.*` / `encoder.up1.*` entries (ref `Encoder`,
+        src/modules.py:30-66); this slot has no parameters, so `strict=True` loads (predict.py:37,78)
+        would reject them as unexpected.  They are skipped here - with a warning, because the trunk
+        they belong to is then NOT what produces this model's input features."""
+        n = sum(1 for k in state_dict if k.startswith(prefix))
+        if n:
+            import warnings
+            warnings.warn("%d checkpoint entries under '%s' belong to the reference's Encoder (EfficientNet trunk + up1), "
+                          "which this model was built without (encoder=None: trunk features are the input); they "
+                          "were ignored.  Pass encoder=lss2_multimodal_nu_amd.Encoder(trunk=...) to load them."
+                          % (n, prefix), stacklevel=3)
+
 
 class _LiftSplatFn(torch.autograd.Function):
     """depthnet -> softmax -> lift -> splat as ONE differentiable op (K2,K5 | K7).
@@ -96,6 +110,25 @@ class _VoxelPoolFn(torch.autograd.Function):
         return gx, None, None, None, None
 
 
+class _histogram_guard:
+    """K3 leaves a point histogram in the cached workspace and K4 counts it back to zero (`vox_count` and
+    `cursor` are zero between calls - no memset launch per step).  If anything raises between the two
+    (a shape check of the depthnet operands, an allocation failure ...) the counters would stay dirty and
+    every later call on that workspace would build overlapping voxel slices; this guard re-zeroes them."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def __enter__(self):
+        return self.ws
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is not None:
+            self.ws.vox_count.zero_()
+            self.ws.cursor.zero_()
+        return False
+
+
 class _LiftSplatMixin:
     """Everything `LSS` and `BEV_TXT` share on the camera->BEV path."""
 
@@ -116,11 +149,15 @@ class _LiftSplatMixin:
         self._stage = None
         self._stage_i = 0
 
-    def _init_lift_splat(self, bsize, grid_conf, data_aug_conf, outC, encoder, precision):
+    def _init_lift_splat(self, bsize, grid_conf, data_aug_conf, outC, encoder, precision, heads=None):
+        """Sub-modules in the reference's registration order (`state_dict` key order, ref :160-176):
+        encoder, [TXT heads via `heads()`], camencode, bevencode."""
         self._init_grid(bsize, grid_conf, data_aug_conf)
         self.camC = 64
         self.D = self.frustum.shape[0]
         self.encoder = encoder if encoder is not None else TrunkFeatures()
+        if heads is not None:
+            heads()
         self.camencode = CamEncode(self.D, self.camC, self.downsample)
         self.bevencode = BevEncode(inC=self.camC, outC=outC, precision=precision)
         self.precision = precision
@@ -231,7 +268,8 @@ class _LiftSplatMixin:
     def get_geometry(self, rots, trans, intrins, post_rots, post_trans):
         """(x,y,z) ego-frame location of every frustum point: B x N x D x fH x fW x 3."""
         ws, geom = self._index_points(rots, trans, intrins, post_rots, post_trans, want_geom=True)
-        ops.bucket_points(ws)  # leave the histogram counters at zero (K4 contract)
+        with _histogram_guard(ws):
+            ops.bucket_points(ws)  # leave the histogram counters at zero (K4 contract)
         return geom
 
     def get_cam_feats(self, x):
@@ -250,8 +288,9 @@ class _LiftSplatMixin:
         P = B * N * D * H * W
         dev = x.device
         ws = self._workspace(P, B * nx[0] * nx[1] * nx[2], dev)
-        ops.geom_to_voxels(geom_feats.detach().float().contiguous(), self.dx.detach(), self.bx.detach(), nx, B, ws)
-        ops.bucket_points(ws)
+        with _histogram_guard(ws):
+            ops.geom_to_voxels(geom_feats.detach().float().contiguous(), self.dx.detach(), self.bx.detach(), nx, B, ws)
+            ops.bucket_points(ws)
         return _VoxelPoolFn.apply(x.reshape(P, C).float().contiguous(), ws, B, nx, C)
 
     def _lift_splat(self, x, rots, trans, intrins, post_rots, post_trans, layout):
@@ -268,8 +307,9 @@ class _LiftSplatMixin:
         ce = self.camencode
         if _needs_autograd(ce, x):
             ws, _ = self._index_points(rots, trans, intrins, post_rots, post_trans)
-            return _LiftSplatFn.apply(x.float(), ce.depthnet.weight, ce.depthnet.bias, ws, dims,
-                                      self._nx_ints(), _PRECISIONS[ce.math], layout)
+            with _histogram_guard(ws):  # K3 ran; K4 runs inside the autograd node, after the operand checks
+                return _LiftSplatFn.apply(x.float(), ce.depthnet.weight, ce.depthnet.bias, ws, dims,
+                                          self._nx_ints(), _PRECISIONS[ce.math], layout)
         # inference: K3 -> K2 -> K4 -> K5 through one native call
         dev = self.frustum.device
         nx = self._nx_ints()
@@ -321,15 +361,18 @@ class BEV_TXT(_LiftSplatMixin, nn.Module):
 
     def __init__(self, bsize, grid_conf, data_aug_conf, outC, encoder=None, precision=None):
         nn.Module.__init__(self)
-        self._init_lift_splat(bsize, grid_conf, data_aug_conf, outC, encoder, precision)
-        self.sceneunder = SceneUnder()
-        self.embeder_f1 = Embedder_f1(in_channels=256, out_channels=32)
-        self.embeder_f2 = Embedder_f2(out_channels=40)
-        self.embeder_lr1 = Embedder_lr1(in_channels=256, out_channels=32)
-        self.embeder_lr2 = Embedder_lr2(out_channels=40)
-        self.predictorf1 = Predictor(num_in=40, classes=4)
-        self.predictorf2 = Predictor(num_in=40, classes=4)
-        self.predictorlr = Predictor(num_in=40, classes=1)
+
+        def heads():
+            self.sceneunder = SceneUnder()
+            self.embeder_f1 = Embedder_f1(in_channels=256, out_channels=32)
+            self.embeder_f2 = Embedder_f2(out_channels=40)
+            self.embeder_lr1 = Embedder_lr1(in_channels=256, out_channels=32)
+            self.embeder_lr2 = Embedder_lr2(out_channels=40)
+            self.predictorf1 = Predictor(num_in=40, classes=4)
+            self.predictorf2 = Predictor(num_in=40, classes=4)
+            self.predictorlr = Predictor(num_in=40, classes=1)
+
+        self._init_lift_splat(bsize, grid_conf, data_aug_conf, outC, encoder, precision, heads)
         self.bevpost = BevPost()
 
     def forward(self, x, rots, trans, intrins, post_rots, post_trans):

@@ -24,7 +24,7 @@ from torch.nn import functional as F
 
 from . import ops
 from .heads import SceneUnder
-from .model_BEV_TXT import _LiftSplatMixin
+from .model_BEV_TXT import _LiftSplatMixin, _histogram_guard
 from .modules import _FoldedConv, _PRECISIONS, _needs_autograd, _to_nhwc, default_precision
 from .tools import QuickCumsum, gen_dx_bx  # noqa: F401  (reference's import surface)
 from .transformer_modules import LightweightBEVTransformer
@@ -314,8 +314,9 @@ class VoVNetBEVTransformer(_LiftSplatMixin, nn.Module):
             return self.voxel_pooling(self.get_geometry(rots, trans, intrins, post_rots, post_trans), cam)
         with ops.region("lift_splat_level"):
             ws, _ = self._index_points(rots, trans, intrins, post_rots, post_trans)
-            depth, feat = self.depth_net.depth_and_context(c3, c4, self.cam_encode)
-            ops.bucket_points(ws, depth, self.D, fH * fW)
+            with _histogram_guard(ws):  # a failure between K3 and K4 must not leave the counters dirty
+                depth, feat = self.depth_net.depth_and_context(c3, c4, self.cam_encode)
+                ops.bucket_points(ws, depth, self.D, fH * fW)
             return ops.lift_splat_fwd(feat, ws, (B, Ncam, self.D, fH, fW, self.C), self._nx_ints(), layout)
 
     def forward(self, imgs, rots, trans, intrins, post_rots, post_trans):

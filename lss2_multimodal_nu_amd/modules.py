@@ -32,11 +32,29 @@ def default_precision():
     return p
 
 
+_warned_eval_autograd = set()
+
+
 def _needs_autograd(module, *inputs):
+    """Does this call have to be differentiable?  (Then it takes the autograd nodes - HIP units where they
+    exist, torch ops otherwise - instead of the fused inference kernels.)  An eval-mode module whose
+    parameters still require grad, called outside `torch.no_grad()`, lands here too: correct, but far
+    slower than the inference path, so that case warns once per module class."""
     if not torch.is_grad_enabled():
         return False
-    return module.training or any(t is not None and t.requires_grad for t in inputs) \
-        or any(p.requires_grad for p in module.parameters())
+    in_grad = any(t is not None and torch.is_tensor(t) and t.requires_grad for t in inputs)
+    if module.training or in_grad:
+        return True
+    if any(p.requires_grad for p in module.parameters()):
+        name = type(module).__name__
+        if name not in _warned_eval_autograd:
+            _warned_eval_autograd.add(name)
+            import warnings
+            warnings.warn("%s is in eval mode but was called with autograd enabled and trainable parameters: this "
+                          "call takes the differentiable path, not the fused HIP inference kernels.  Wrap inference "
+                          "in torch.no_grad() (as predict.py / get_val_info do)." % name, stacklevel=3)
+        return True
+    return False
 
 
 class _Conv3x3Fn(torch.autograd.Function):
@@ -518,6 +536,22 @@ class Encoder(nn.Module):
     def forward(self, x):
         return self.get_eff_depth(x)
 
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        """Without a trunk, the `trunk.*` entries of a reference checkpoint (the EfficientNet weights) have
+        no home here; they are dropped with a warning instead of failing a `strict=True` load of the
+        whole model (`up1.*` still loads strictly)."""
+        if getattr(self, "trunk", None) is None:
+            drop = [k for k in state_dict if k.startswith(prefix + "trunk.")]
+            if drop:
+                import warnings
+                warnings.warn("%d '%strunk.*' checkpoint entries ignored: this Encoder was built without a trunk"
+                              % (len(drop), prefix), stacklevel=3)
+                for k in drop:
+                    del state_dict[k]  # load_state_dict works on its own shallow copy of the caller's dict
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
 
 class BasicBlock(nn.Module):
     """torchvision resnet BasicBlock (expansion 1): conv3x3-BN-ReLU-conv3x3-BN,
@@ -627,6 +661,7 @@ class BevEncode(nn.Module):
     def invalidate_plan(self):
         """Drop the cached launch lists (called whenever parameters may have changed)."""
         self._plans = {}
+        self.__dict__.pop("_stamp_mods", None)
 
     def train(self, mode=True):
         self.invalidate_plan()
@@ -641,8 +676,25 @@ class BevEncode(nn.Module):
         return super().load_state_dict(*a, **k)
 
     def _plan_stamp(self):
-        return tuple(f._key(0)[1:] for f in (self._stem, self._up2a, self._up2b, self.up1._f0, self.up1._f1)) + \
-            tuple(b._f1._key(0)[1:] + b._f2._key(0)[1:] for l in (self.layer1, self.layer2, self.layer3) for b in l)
+        """(in-place version, storage pointer) of EVERY tensor a recorded plan holds a packed / folded copy
+        of: all conv weights (the 1x1 downsamples included), every BatchNorm's affine pair and running
+        statistics, the head's weight and bias.  Compared on every replay (~25 us of host time), so an
+        in-place edit, an optimizer step, a re-assigned Parameter or a `load_state_dict` on ANY ancestor
+        module (which never calls this module's own `load_state_dict`) can not be served from a stale plan."""
+        mods = self.__dict__.get("_stamp_mods")
+        if mods is None:
+            mods = self.__dict__["_stamp_mods"] = [m for m in self.modules()
+                                                   if isinstance(m, (nn.Conv2d, nn.BatchNorm2d))]
+        out = []
+        for m in mods:
+            for t in m._parameters.values():
+                if t is not None:
+                    out.append(t._version)
+                    out.append(t.data_ptr())
+            for t in m._buffers.values():
+                if t is not None:
+                    out.append(t._version)
+        return tuple(out)
 
     def forward_nhwc(self, x, dt):
         """HIP path: x (B,X,Y,inC) channels-last activations in dt -> (B,outC,X,Y) fp32 NCHW.
@@ -653,9 +705,8 @@ class BevEncode(nn.Module):
                 return self._forward_nhwc(x, dt)
             key = (tuple(x.shape), x.device)
             ent = self._plans.get(key)
-            self._calls = getattr(self, "_calls", 0) + 1
-            if ent is not None and self._calls % 64 == 0 and ent[1] != self._plan_stamp():
-                ent = None  # parameters were modified in place since the plan was built
+            if ent is not None and ent[1] != self._plan_stamp():
+                ent = None  # parameters were modified since the plan was built (checked on every call)
             if ent is None:
                 rec = ops.ConvRecorder()
                 ops.set_recorder(rec)

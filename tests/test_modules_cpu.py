@@ -128,3 +128,111 @@ def test_bev_txt_constructs_with_reference_heads():
     keys = set(k.split(".")[0] for k in m.state_dict())
     assert {"sceneunder", "embeder_f1", "embeder_f2", "embeder_lr1", "embeder_lr2", "predictorf1", "predictorf2",
             "predictorlr", "bevpost", "camencode", "bevencode", "frustum"} <= keys
+
+
+# ---- BEV_TXT / only-BEV variants against the reference's own forward (fixture g13, tools/gen_golden_heads.py) ----
+def _heads_fixture(golden, tag):
+    from oracle import vovnet_oracle as vo  # seeded parameter generator shared with the fixture script
+    g = golden("g13_bevtxt_heads")
+    keys = [str(k) for k in g[tag + "_keys"]]
+    shapes = [tuple(int(d) for d in str(s).split(",")) if str(s) else () for s in g[tag + "_shapes"]]
+    dtypes = [str(d) for d in g[tag + "_dtypes"]]
+    head = [(k, s) for k, s in zip(keys, shapes) if k.split(".")[0] not in ("dx", "bx", "nx", "frustum", "camencode")]
+    return g, keys, shapes, dtypes, vo.seeded_state(head, int(g[tag + "_seed"]))
+
+
+@pytest.mark.parametrize("tag", ["txt", "onlybev"])
+def test_bevtxt_variants_state_dict_layout_is_the_references(golden, tag):
+    """Keys, ORDER, shapes and dtypes of every entry outside `encoder.*` / `bevencode.*` equal the list the
+    reference's own modules produced (the reference registers bevencode between camencode and bevpost)."""
+    g, keys, shapes, dtypes, _ = _heads_fixture(golden, tag)
+    make = L.compile_model_bevtxt if tag == "txt" else L.compile_model_onlybev
+    m = make(2, GRID, AUG, 4)
+    sd = m.state_dict()
+    mine = [(k, tuple(v.shape), str(v.dtype)) for k, v in sd.items() if not k.startswith(("encoder.", "bevencode."))]
+    assert mine == list(zip(keys, shapes, dtypes))
+    order = [k.split(".")[0] for k in sd]
+    assert order.index("camencode") < order.index("bevencode") < order.index("bevpost")  # ref __init__ order
+
+
+@pytest.mark.parametrize("tag", ["txt", "onlybev"])
+def test_bevtxt_variants_txt_half_equals_reference_forward(golden, tag):
+    """The TXT half (crop [:, :, 60:140, 56:144], BevPost, camera selection, embedders, predictors, concat
+    order) against the outputs of the reference's forward code on the same seeded weights and inputs; the
+    BEV map is the fixture's (the camera->BEV half needs the GPU and is tested in test_modules_gpu.py)."""
+    g, _, _, _, state = _heads_fixture(golden, tag)
+    make = L.compile_model_bevtxt if tag == "txt" else L.compile_model_onlybev
+    m = make(int(g["B"]), GRID, AUG, 4).eval()
+    missing, unexpected = m.load_state_dict(state, strict=False)
+    assert not unexpected and all(k.split(".")[0] in ("dx", "bx", "nx", "frustum", "camencode", "bevencode")
+                                  for k in missing)
+    rs = np.random.RandomState
+    x = torch.from_numpy(rs(int(g["seed_x"])).randn(int(g["B"]) * 6, 512, 8, 22).astype(np.float32))
+    bev = torch.from_numpy(rs(int(g["seed_bev"])).randn(int(g["B"]), 4, 200, 200).astype(np.float32))
+    m._bev = lambda *a: bev
+    with torch.no_grad():
+        bev_o, act, desc = m(x, None, None, None, None, None)
+    assert bev_o is bev
+    np.testing.assert_allclose(act.numpy(), g[tag + "_act"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(desc.numpy(), g[tag + "_desc"], rtol=1e-4, atol=1e-5)
+
+
+def test_onlybev_heads_backpropagate_into_the_bev_map():
+    """ref src/model_baseline.py:283: the only-BEV variant does NOT detach the crop (model_BEV_TXT.py:285 does)."""
+    for make, expect in ((L.compile_model_onlybev, True), (L.compile_model_bevtxt, False)):
+        m = make(1, GRID, AUG, 4).eval()
+        bev = torch.randn(1, 4, 200, 200, requires_grad=True)
+        m._bev = lambda *a: bev
+        _, act, desc = m(torch.randn(6, 512, 8, 22), None, None, None, None, None)
+        (act.sum() + desc.sum()).backward()
+        got = bev.grad is not None and float(bev.grad.abs().sum()) > 0
+        assert got == expect
+        if expect:  # only the crop receives gradient
+            mask = torch.ones_like(bev, dtype=torch.bool)
+            mask[:, :, 60:140, 56:144] = False
+            assert float(bev.grad[mask].abs().sum()) == 0.0
+
+
+def test_strict_load_of_a_reference_checkpoint_with_trunk_entries(lss):
+    """predict.py:37,78 load with strict=True; a reference checkpoint also carries `encoder.*` entries."""
+    sd = dict(lss.state_dict())
+    sd["encoder.trunk._conv_stem.weight"] = torch.zeros(48, 3, 3, 3)
+    sd["encoder.up1.conv.0.weight"] = torch.zeros(512, 608, 3, 3)
+    m = L.compile_model_lss(2, GRID, AUG, 4)
+    with pytest.warns(UserWarning, match="Encoder"):
+        m.load_state_dict(sd, strict=True)
+    # with the Encoder mirror in the slot, up1.* loads strictly and only the (absent) trunk's entries are dropped
+    m2 = L.compile_model_lss(2, GRID, AUG, 4, encoder=L.Encoder())
+    sd2 = dict(m2.state_dict())
+    sd2["encoder.trunk._conv_stem.weight"] = torch.zeros(48, 3, 3, 3)
+    with pytest.warns(UserWarning, match="trunk"):
+        m2.load_state_dict(sd2, strict=True)
+    del sd2["encoder.up1.conv.0.weight"]
+    with pytest.raises(RuntimeError), pytest.warns(UserWarning):
+        m2.load_state_dict(sd2, strict=True)
+
+
+def test_plan_stamp_sees_every_folded_tensor(lss):
+    """the launch-plan stamp must change for an in-place edit of ANY conv / BatchNorm tensor,
+    the 1x1 downsamples included, and for a load_state_dict on the PARENT model."""
+    be = lss.bevencode
+    base = be._plan_stamp()
+    with torch.no_grad():
+        for name, t in list(be.named_parameters()) + list(be.named_buffers()):
+            if name.endswith("num_batches_tracked"):
+                continue
+            before = be._plan_stamp()
+            t.add_(0)
+            assert be._plan_stamp() != before, name
+    assert be._plan_stamp() != base
+    before = be._plan_stamp()
+    lss.load_state_dict({k: v.clone() for k, v in lss.state_dict().items()})
+    assert be._plan_stamp() != before
+
+
+def test_eval_mode_call_with_grad_enabled_warns(lss):
+    from lss2_multimodal_nu_amd import modules as M
+    M._warned_eval_autograd.discard("BevEncode")
+    lss.bevencode.eval()
+    with pytest.warns(UserWarning, match="no_grad"), torch.enable_grad():
+        lss.bevencode(torch.randn(1, 64, 16, 16))
