@@ -10,7 +10,11 @@ Multi-GPU: one process per GPU, samples sharded across ranks (data parallel,
 no data-path collective on the inference path) -> weak scaling.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...      # bare: spawns N ranks itself (torch.distributed.run child, before any GPU call)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # or launched by a driver
+
+    --workload config1|config2|hires  = BASELINE configs[0] shapes (B=1) | configs[1] (default, the metric's
+                                        workload; also the per-GPU shape of configs[2]) | configs[4] per-GPU shapes
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel =
 the MFMA convs), `roofline_l1` (the HBM-bound lift-splat kernel), `levels`
@@ -77,6 +81,48 @@ def pmc_traffic(kernel_prefix, grid=None):
     return (tot / n, os.path.basename(files[-1])) if n else (None, None)
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_command(n, argv, port=None):
+    """The command a bare `python bench.py --gpus N` turns itself into: one rank per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port or _free_port()),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args):
+    """Bare multi-GPU invocation: this process has NOT touched the GPU (torch is imported, nothing else), so it
+    may start the ranks as children and relay their output; it never re-executes itself in place."""
+    import subprocess
+    cmd = launch_command(args.gpus, sys.argv[1:])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required for RCCL on this driver stack
+    env.setdefault("OMP_NUM_THREADS", "2")
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
+
+
+def dry_launch(world, rank):
+    """`--dry-launch`: rendezvous + one all-reduce over gloo on the CPU, then the JSON line - the launcher and
+    the rank plumbing without a GPU (tests/test_bench_launcher.py)."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.ones(1) * (rank + 1)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_seen": int(dist.get_world_size()),
+                          "rank_sum": float(t[0]), "backend": dist.get_backend()}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,9 +130,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="samples per GPU per step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--workload", default="config2", choices=["config2", "hires"],
-                    help="config2 = BASELINE configs[1] (default, the metric's workload); hires = configs[4] "
-                         "per-GPU shapes (6 x 704x256, D=60, 400x400 BEV, batch 2/GPU)")
+    ap.add_argument("--workload", default="config2", choices=["config1", "config2", "hires"],
+                    help="config1 = BASELINE configs[0] shapes (model_baseline LSS, 1 sample) on the GPU; config2 = "
+                         "configs[1] (default, the metric's workload, = the per-GPU shape of configs[2]); hires = "
+                         "configs[4] per-GPU shapes (6 x 704x256, D=60, 400x400 BEV, batch 2/GPU)")
+    ap.add_argument("--dry-launch", action="store_true", help="launcher / rendezvous check on the CPU (gloo), no GPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--two-streams", action="store_true",
@@ -94,11 +142,15 @@ def main():
     ap.add_argument("--train-steps", type=int, default=8)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_launch:
+        return dry_launch(world, rank)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # The per-step host work of the GPU legs is a handful of 3x3 inverses and one pinned copy: it
     # gains nothing from an intra-op pool, and with one rank per GPU on a shared node 8 x 16
@@ -125,13 +177,18 @@ def main():
 
     B = args.batch
     grid, aug, fH, fW, X, Y = GRID, AUG, 8, 22, 200, 200
+    compile_lss = L.compile_model_lss
+    if args.workload == "config1":
+        from lss2_multimodal_nu_amd import model_baseline  # BASELINE configs[0] names model_baseline's LSS
+        compile_lss = model_baseline.compile_model_lss
+        B = 1 if args.batch == 4 else args.batch
     if args.workload == "hires":
         grid = dict(xbound=[-50.0, 50.0, 0.25], ybound=[-50.0, 50.0, 0.25], zbound=[-10.0, 10.0, 20.0],
                     dbound=[1.0, 61.0, 1.0])
         aug, fH, fW, X, Y = {"final_dim": (256, 704), "Ncams": 6}, 16, 44, 400, 400
         B = 2 if args.batch == 4 else args.batch
     torch.manual_seed(0)
-    model = L.compile_model_lss(B, grid, aug, 4, precision=args.precision).to(dev).eval()
+    model = compile_lss(B, grid, aug, 4, precision=args.precision).to(dev).eval()
     D, C = model.D, model.camC
     Z = 1
     # per-rank shard of the global batch: different samples (seeded by rank), same shapes
@@ -197,8 +254,19 @@ def main():
             dt_2s = time.perf_counter() - t2
 
     tmax = torch.tensor([dt, dt_l1, dt_2s], dtype=torch.float64, device=dev)
+    per_rank = [args.steps * B / dt]
+    comm = {"backend": "none", "ranks": 1}
     if dist is not None:
+        mine = torch.tensor([args.steps * B / dt], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(t[0]) for t in every]
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones)  # a real collective over the communicator: counts the ranks that answered
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        comm = {"backend": dist.get_backend(), "ranks": int(ones[0]),
+                "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if not rehearse else None,
+                "devices": "all ranks on cuda:0 (LSS_BENCH_REHEARSE)" if rehearse else "one GPU per rank (LOCAL_RANK)"}
     dt, dt_l1, dt_2s = float(tmax[0]), float(tmax[1]), float(tmax[2])
     frames = args.steps * B * world
     fps = frames / dt
@@ -223,11 +291,14 @@ def main():
         "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32",
         "data": "synthetic (seeded N(0,1) trunk features 6x512x8x22 per frame, nuScenes-like 6-camera rig "
                 "with train-time augmentation, random-init weights)",
-        "config": {"workload": ("BASELINE configs[1]: model_BEV_TXT LSS hot path, batch=%d/GPU, 6 cams 352x128, "
-                                "D=41, 200x200x64 BEV -> BevEncode -> 200x200x4, trunk (EfficientNet) not included: "
-                                "features are the input" % B) if args.workload == "config2" else
-                               ("BASELINE configs[4] per-GPU shapes: batch=%d/GPU, 6 cams 704x256, D=60, 400x400x64 BEV "
-                                "-> BevEncode -> 400x400x4" % B),
+        "config": {"workload": {"config2": "BASELINE configs[1]: model_BEV_TXT LSS hot path, batch=%d/GPU, 6 cams 352x128, "
+                                           "D=41, 200x200x64 BEV -> BevEncode -> 200x200x4, trunk (EfficientNet) not included: "
+                                           "features are the input" % B,
+                                "config1": "BASELINE configs[0] shapes on the GPU: model_baseline LSS, batch=%d, 6 cams 352x128, "
+                                           "D=41, 200x200x64 BEV -> BevEncode -> 200x200x4 (the CPU leg of that config is "
+                                           "`cpu_baseline`)" % B,
+                                "hires": "BASELINE configs[4] per-GPU shapes: batch=%d/GPU, 6 cams 704x256, D=60, 400x400x64 BEV "
+                                         "-> BevEncode -> 400x400x4" % B}[args.workload],
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d (sample-sharded, no collective)" % world,
                    "precision": args.precision, "calibration": "CPU tensors per step; 3x3 inverses on host (exact-index contract), 576 floats passed in the kernel arguments (no H2D copy)"},
         "roofline": {"kernel": "conv_lds_kernel (+3 conv_direct_kernel): the 18 BevEncode launches of a step, one HIP-event "
@@ -244,6 +315,7 @@ def main():
                         "launches": n_spl * 5,
                         "avg_us": ms_spl * 1e3 / max(n_spl * 5, 1), "level_us": ms_spl * 1e3 / max(n_spl, 1),
                         "bytes_per_step": splat_bytes_step},
+        "per_rank_fps": per_rank, "comm": comm,
         "levels": {"L2_hot_path_fps": fps,
                    "L1_lift_splat_fps": frames / dt_l1, "L1_ms_per_step": dt_l1 / args.steps * 1e3,
                    "L1_algorithmic_GBs": l1_bytes_step * args.steps * world / dt_l1 / 1e9,
@@ -260,7 +332,7 @@ def main():
         out["train"] = train_leg(args, model, feats, calib, dev, dist, world, B)
 
     # ---- CPU baseline: the oracle (op-for-op torch port of the reference) on this host ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "config2":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("config2", "config1"):
         out["cpu_baseline"] = cpu_baseline(model, feats, calib, B)
 
     if rank == 0:
@@ -276,7 +348,7 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     from lss2_multimodal_nu_amd import dp
     torch.manual_seed(0)
     m = L.compile_model_lss(B, GRID, AUG, 4, precision=args.precision).to(dev).train()
-    bucket = dp.GradBucket(m.parameters())
+    bucket = dp.make_bucket(m)  # every p.grad is a view of one flat buffer; all-reduce starts inside backward
     opt = torch.optim.Adam(bucket.params, lr=1e-4, weight_decay=1e-8)  # ref: train.py:42
     tgt = torch.randint(0, 4, (B, 200, 200), device=dev)
     weight = torch.tensor([1.0, 10.0, 5.0, 10.0], device=dev)         # ref: src/tools.py:234
@@ -299,14 +371,8 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
 
     wrapped = _Amp(m)
 
-    def one():
-        if dist is not None:
-            dp.train_step(wrapped, bucket, opt, loss_fn, (feats,) + tuple(calib))
-        else:
-            opt.zero_grad(set_to_none=True)
-            loss_fn(wrapped(feats, *calib)).backward()
-            torch.nn.utils.clip_grad_norm_(bucket.params, 5.0)      # ref: train.py:64
-            opt.step()
+    def one():  # ref: train.py:49-66 (zero_grad, forward, loss, backward, clip 5.0, Adam) + the DP all-reduce
+        dp.train_step(wrapped, bucket, opt, loss_fn, (feats,) + tuple(calib), clip=5.0)
 
     for _ in range(2):
         one()
@@ -325,6 +391,9 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     dt = float(dt[0])
     return {"samples_per_s": args.train_steps * B * world / dt, "ms_per_step": dt / args.train_steps * 1e3,
             "steps": args.train_steps, "grad_bucket_MB": bucket.numel * 4 / 1e6,
+            "grad_buckets": [(hi - lo) * 4 / 1e6 for lo, hi, _ in bucket.buckets],
+            "allreduce": ("direct RCCL (lss_allreduce_bucket)" if bucket._direct is not None else
+                          ("torch.distributed %s" % dist.get_backend() if dist is not None else "none (1 rank)")),
             "amp_bf16": amp,
             "note": "lift-splat fwd/bwd native HIP (fp32); under bf16 autocast every 3x3/s1 conv + BatchNorm(train) + "
                     "residual + ReLU unit of BevEncode (95 % of its FLOPs) is one HIP autograd node: conv fwd / dgrad / "

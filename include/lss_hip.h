@@ -41,6 +41,8 @@ extern "C" {
 #define LSS_E_LAYOUT (-3)    /* unknown layout / dtype enum           */
 #define LSS_E_ALIGN (-4)     /* pointer not aligned as required       */
 #define LSS_E_WORKSPACE (-5) /* workspace too small                   */
+/* RCCL entry points: LSS_E_RCCL_BASE = librccl could not be resolved; LSS_E_RCCL_BASE - r = ncclResult_t r */
+#define LSS_E_RCCL_BASE (-100)
 
 /* BEV tensor memory layouts */
 #define LSS_BEV_NCHW_F32 0  /* (B, Z*C, X, Y) contiguous fp32 - the reference's layout */
@@ -470,6 +472,24 @@ int lss_lift_splat_forward_hostcal(const float* frustum, const float* calib_host
                                    int Z, int32_t* voxel, int32_t* vox_count, int32_t* vox_list,
                                    int32_t* entries, int32_t* cursor, float* depth, float* feat,
                                    void* bev, int layout, void* stream);
+
+/* ---- data-parallel gradient step (the reference has no collective on this path: its loop is
+ * `loss.backward(); clip_grad_norm_(5.0); opt.step()`, train.py:63-65, on one device) --------------------------
+ * One process per GPU; the flat fp32 gradient buffer (every p.grad is a view of it) is summed in place over
+ * the ranks of an RCCL communicator (xGMI), enqueued on `stream` behind the backward kernels that wrote it.
+ * RCCL is resolved at run time from the librccl already loaded in the process (PyTorch-ROCm's own copy), else
+ * from the system's librccl.so: this library has no link-time dependency on it.
+ *   lss_rccl_get_unique_id : rank 0 fills `id_host` (lss_rccl_unique_id_bytes() = 128 bytes) and hands it to the
+ *                            other ranks by any out-of-band channel (dp.py: torch.distributed's store);
+ *   lss_rccl_comm_init     : collective over all `nranks` processes, the calling process's current HIP device;
+ *   lss_allreduce_bucket   : buf[0..n) <- sum over ranks, in place, asynchronous on `stream`;
+ *   lss_rccl_comm_destroy  : releases the communicator. */
+size_t lss_rccl_unique_id_bytes(void);
+int lss_rccl_version(int* version);
+int lss_rccl_get_unique_id(void* id_host);
+int lss_rccl_comm_init(const void* id_host, int nranks, int rank, void** comm);
+int lss_allreduce_bucket(void* comm, float* buf, long long n, void* stream);
+int lss_rccl_comm_destroy(void* comm);
 
 /* Layout / dtype conversion helpers between the reference's NCHW fp32 tensors
  * and the conv path's NHWC tensors. */

@@ -69,6 +69,12 @@ SIGNATURES = {
     "lss_conv2d_s2_dual_fwd": (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
     "lss_conv2d_sequence": (_i, [_vp, _i, _vp]),
     "lss_lift_splat_forward": (_i, [_vp] * 10 + [_i] * 10 + [_vp] * 8 + [_i, _i, _vp]),
+    "lss_rccl_unique_id_bytes": (_sz, []),
+    "lss_rccl_version": (_i, [_vp]),
+    "lss_rccl_get_unique_id": (_i, [_vp]),
+    "lss_rccl_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "lss_allreduce_bucket": (_i, [_vp, _vp, ctypes.c_longlong, _vp]),
+    "lss_rccl_comm_destroy": (_i, [_vp]),
     "lss_nchw_f32_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "lss_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }
@@ -111,7 +117,7 @@ def lib():
 def check(code, what):
     if code != 0:
         msg = lib().lss_error_string(code).decode()
-        exc = ValueError if code < 0 else LssNativeError
+        exc = ValueError if -100 < code < 0 else LssNativeError  # argument checks vs HIP / RCCL run-time errors
         raise exc("%s failed (%d): %s" % (what, code, msg))
 
 
@@ -128,3 +134,25 @@ def stream():
     """hipStream_t of torch's current stream on the current device (raw handle: the
     Python-level torch.cuda.current_stream() costs ~9 us per call, this ~0.3 us)."""
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+
+
+def rccl_unique_id():
+    """128-byte RCCL unique id (bytes) for `rccl_comm_init`; create on one rank, ship to the others."""
+    n = lib().lss_rccl_unique_id_bytes()
+    buf = ctypes.create_string_buffer(n)
+    check(lib().lss_rccl_get_unique_id(buf), "lss_rccl_get_unique_id")
+    return buf.raw
+
+
+def rccl_comm_init(uid, nranks, rank):
+    """Collective: every rank calls it with the same id.  Returns the communicator handle (c_void_p)."""
+    comm = ctypes.c_void_p()
+    check(lib().lss_rccl_comm_init(ctypes.create_string_buffer(uid, len(uid)), nranks, rank, ctypes.byref(comm)),
+          "lss_rccl_comm_init")
+    return comm
+
+
+def rccl_version():
+    v = ctypes.c_int()
+    check(lib().lss_rccl_version(ctypes.byref(v)), "lss_rccl_version")
+    return v.value

@@ -30,6 +30,7 @@ SOURCES = {
     "conv_grad.hip": [],
     "bn_train.hip": [],
     "loss.hip": [],
+    "rccl_bucket.hip": [],  # host code only: RCCL resolved with dlsym at run time (no -lrccl)
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-variable",
           "-Wno-unused-but-set-variable"]
@@ -70,7 +71,7 @@ def build(force=False, verbose=True, save_temps=False):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)
     if procs or force or not os.path.exists(LIB):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -309,13 +309,16 @@ static int ffn_launch(bool proj, const void* x, const void* w1, const float* b1,
         reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y_ln) | reinterpret_cast<uintptr_t>(ln_gamma) |
         reinterpret_cast<uintptr_t>(ln_beta) | reinterpret_cast<uintptr_t>(res)) & 15) != 0)
     return LSS_E_ALIGN;
-  static bool attr_set[2] = {false, false};
+  // the dynamic-LDS limit is a per-DEVICE function attribute: remember it per (device, kernel)
+  static bool attr_set[64][2] = {};
   const void* fn = proj ? reinterpret_cast<const void*>(ffn_fused_kernel<true>)
                         : reinterpret_cast<const void*>(ffn_fused_kernel<false>);
-  if (!attr_set[proj]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+  if (dev < 0 || !attr_set[dev][proj]) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_set[proj] = true;
+    if (dev >= 0) attr_set[dev][proj] = true;
   }
   FfnArgs a;
   a.x = reinterpret_cast<const unsigned short*>(x);

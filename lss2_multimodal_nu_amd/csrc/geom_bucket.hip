@@ -4,7 +4,8 @@
 // of a point has to equal the reference's bit for bit, and torch-CPU evaluates
 // every 3x3 * 3 product of get_geometry (ref: src/model_BEV_TXT.py:60,67) as
 // ((m0*p0 + m1*p1) + m2*p2) with each mul/add rounded to fp32.
-// tests/test_build.py greps the ISA of points_to_voxels_kernel for v_fma/v_mac.
+// tests/test_build_abi.py compiles this file to ISA and checks that the two geometry -> voxel-id kernels hold
+// no v_fma / v_fmac / v_mac / v_mad.
 #include "depthnet_body.h"
 
 namespace {
@@ -330,8 +331,10 @@ extern "C" const char* lss_error_string(int code) {
     case LSS_E_LAYOUT: return "lss: unknown layout or dtype";
     case LSS_E_ALIGN: return "lss: pointer not sufficiently aligned";
     case LSS_E_WORKSPACE: return "lss: workspace too small";
+    case LSS_E_RCCL_BASE: return "lss: librccl could not be resolved in this process";
     default: break;
   }
+  if (code < LSS_E_RCCL_BASE && code > LSS_E_RCCL_BASE - 64) return "lss: RCCL call failed (ncclResult_t = LSS_E_RCCL_BASE - code)";
   if (code > 0) return hipGetErrorString((hipError_t)code);
   return "lss: unknown error";
 }

@@ -17,9 +17,12 @@
     if ((v) <= 0) return LSS_E_SHAPE; \
   } while (0)
 
+// Status of the launch just enqueued.  hipPeekAtLastError, not hipGetLastError: the per-thread error is
+// shared with the host framework's own HIP calls, and reading it here must not clear an error the framework
+// has yet to see (nor would clearing make a sticky error go away).
 static inline int lss_launch_status() {
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : (int)e;
+  hipError_t e = hipPeekAtLastError();
+  return (e == hipSuccess || e == hipErrorNotReady) ? 0 : (int)e;  // NotReady: a pending event query, not a launch error
 }
 
 static inline hipStream_t lss_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -12,6 +12,7 @@ No dataset code here (nuScenes access stays in the reference's `src/data.py`).
 """
 import numpy as np
 import torch
+import torch.utils.data
 
 
 def get_rot(h):
@@ -102,16 +103,22 @@ class CalibrationPack:
                 buf[21 * n:24 * n].view(B, N, 3))
 
 
-def prepare_calibration(rots, trans, intrins, post_rots, post_trans, pin=None):
+def prepare_calibration(rots, trans, intrins, post_rots, post_trans, pin=False):
     """Loader-side half of `LSS.forward`'s calibration handling: do the host inverses once per sample
     batch (in a DataLoader worker or collate_fn) and pack everything for one H2D copy.
-    Returns a `CalibrationPack` to pass as the model's `rots` argument."""
+    Returns a `CalibrationPack` to pass as the model's `rots` argument.
+
+    `pin` defaults to False: page-locking needs a HIP context, which a forked DataLoader worker must not
+    create ("Cannot re-initialize CUDA in forked subprocess"), and pinning does not survive the worker ->
+    main-process queue anyway.  Let `DataLoader(pin_memory=True)` pin the pack's buffer in the main process, or
+    call this with pin=True there.  (With <= 36 cameras the buffer rides in the kernel arguments and is never
+    copied at all: pinning is irrelevant on that path.)"""
     inv_pr, comb = calib_matrices(rots, intrins, post_rots)
     B, N = trans.shape[:2]
     buf = torch.cat([inv_pr.reshape(-1), comb.reshape(-1), post_trans.detach().float().cpu().reshape(-1),
                      trans.detach().float().cpu().reshape(-1)])
-    if pin is None:
-        pin = torch.cuda.is_available()
     if pin:
+        if torch.utils.data.get_worker_info() is not None:
+            raise RuntimeError("prepare_calibration(pin=True) inside a DataLoader worker: pin in the main process")
         buf = buf.pin_memory()
     return CalibrationPack(buf, (B, N))

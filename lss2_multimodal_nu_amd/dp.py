@@ -1,14 +1,30 @@
 """Data parallelism for the hot path: one process per GPU, samples sharded across
-ranks, one flat fp32 gradient bucket all-reduced per step.
+ranks, gradients averaged through ONE flat fp32 buffer.
 
 The reference has no distributed code at all; this mirrors what
 its single-GPU loop does after `loss.backward()` (`train.py:63-65`) - all-reduce,
-`clip_grad_norm_(5.0)`, `opt.step()` - with the all-reduce being ONE RCCL
-collective over xGMI (backend "nccl" on ROCm) instead of one per parameter:
-18.6 MB for CamEncode + BevEncode, i.e. the latency-bound small-message regime
-where fewer, larger messages win.  Works with any torch.distributed backend
-(tests run it on gloo/CPU with world_size 2).
+`clip_grad_norm_(5.0)`, `opt.step()`.
+
+Design for MI355X / RCCL over xGMI (point-to-point links, per-link-bound rings; the 18.6 MB of
+CamEncode + BevEncode gradients sit in the latency-bound small-message regime, so few large
+messages beat one per parameter):
+
+* every `p.grad` IS a view into the flat buffer (no pack / unpack copy kernels: autograd
+  accumulates straight into it; the buffer is cleared by one memset per step);
+* the buffer is cut into a few contiguous buckets in REVERSE registration order (= the order in
+  which backward produces gradients: BevEncode's up2/up1 first, CamEncode last); a
+  post-accumulate hook counts a bucket's parameters and starts its all-reduce (async, on RCCL's
+  own stream) the moment the last one is written, so the collective of the BevEncode tail
+  overlaps the rest of backward;
+* gradient clipping is two kernels on the flat buffer (norm, scale) instead of a foreach over
+  every parameter.
+
+Works with any torch.distributed backend (tests run it on gloo/CPU with world_size 2).  With
+`LSS_DP_DIRECT_RCCL=1` the collective goes through this package's own RCCL communicator and the
+C-ABI entry `lss_allreduce_bucket` (include/lss_hip.h) instead of torch's process group.
 """
+import os
+
 import torch
 
 
@@ -23,55 +39,166 @@ def shard_range(global_batch, rank, world):
 
 
 class GradBucket:
-    """Flat fp32 buffer holding every trainable parameter's gradient back to back."""
+    """Flat fp32 buffer that every trainable parameter's `.grad` is a view of."""
 
-    def __init__(self, params):
+    def __init__(self, params, n_buckets=3, group=None, overlap=True):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
+        if any(p.dtype != torch.float32 for p in self.params):
+            raise ValueError("GradBucket holds fp32 master gradients")
         dev = self.params[0].device
+        self.group = group
+        self.overlap = overlap
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-
-    def pack(self):
-        o = 0
-        for p in self.params:
+        # layout: REVERSE registration order, so that bucket 0 (the first to complete during
+        # backward) is one contiguous slice
+        order = list(reversed(self.params))
+        self.views, o = {}, 0
+        target = -(-self.numel // max(1, n_buckets))
+        self.buckets = []  # [start, end, n_params]
+        self._bucket_of = {}
+        cur = [0, 0, 0]
+        for p in order:
             n = p.numel()
-            if p.grad is None:
-                self.flat[o:o + n].zero_()
-            else:
-                self.flat[o:o + n].copy_(p.grad.reshape(-1))
+            self.views[p] = self.flat[o:o + n].view_as(p)
             o += n
+            cur[1], cur[2] = o, cur[2] + 1
+            self._bucket_of[p] = len(self.buckets)
+            if o - cur[0] >= target and len(self.buckets) < n_buckets - 1:
+                self.buckets.append(cur)
+                cur = [o, o, 0]
+        if cur[2]:
+            self.buckets.append(cur)
+        self._ready = [0] * len(self.buckets)
+        self._work = []
+        self._fired = set()
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._direct = None
+        self.attach()
 
-    def unpack(self):
-        o = 0
+    # -- the views --------------------------------------------------------------
+    def attach(self):
+        """(Re-)point every p.grad at its slice (after something replaced or dropped it)."""
         for p in self.params:
-            n = p.numel()
-            g = self.flat[o:o + n].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            o += n
+            if p.grad is not self.views[p]:
+                p.grad = self.views[p]
 
-    def all_reduce_mean(self, group=None):
-        """grads <- mean over ranks (the loss is a per-rank mean, so the global-batch
-        gradient is the mean of the per-rank gradients)."""
+    def zero(self):
+        """Start of a step: one memset instead of `opt.zero_grad()` (which would drop the views)."""
+        self.flat.zero_()
+        self._ready = [0] * len(self.buckets)
+        self._work = []
+        self._fired = set()
+        self.attach()
+
+    # -- collective -------------------------------------------------------------
+    def _world(self):
         import torch.distributed as dist
-        world = dist.get_world_size(group)
-        self.pack()
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def _launch(self, b):
+        import torch.distributed as dist
+        lo, hi, _ = self.buckets[b]
+        seg = self.flat[lo:hi]
+        if self._direct is not None:
+            self._direct.all_reduce_sum(seg)
+            return
+        self._work.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _on_grad(self, p):
+        if p.grad is not self.views[p]:
+            # autograd installed its own tensor (the view had been dropped): fold it in and re-attach
+            self.views[p].add_(p.grad)
+            p.grad = self.views[p]
+        self._fired.add(p)
+        b = self._bucket_of[p]
+        self._ready[b] += 1
+        if self.overlap and self._ready[b] == self.buckets[b][2] and self._world() > 1:
+            self._launch(b)
+            self._ready[b] = -1  # launched
+
+    def use_direct_rccl(self, comm):
+        """Route the collective through `lss_allreduce_bucket` on this package's own communicator."""
+        self._direct = comm
+
+    def all_reduce_mean(self):
+        """grads <- mean over ranks (the loss is a per-rank mean, so the global-batch gradient is
+        the mean of the per-rank gradients).  Buckets whose all-reduce the backward hooks already
+        started are only waited for."""
+        world = self._world()
         if world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            for b in range(len(self.buckets)):
+                if self._ready[b] != -1:  # unused parameters in it, or overlap off
+                    self._launch(b)
+                    self._ready[b] = -1
+            for w in self._work:
+                w.wait()
+            self._work = []
             self.flat.div_(world)
-        self.unpack()
+
+    def clip_grad_norm_(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_(params, max_norm) (ref train.py:64) on the flat buffer: the
+        same total 2-norm (the buffer holds exactly the gradients) and the same `max_norm / (norm +
+        1e-6)` scale clamped to 1, in two kernels and without a host sync."""
+        total = torch.linalg.vector_norm(self.flat)
+        self.flat.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
+        return total
+
+    def hide_unused(self):
+        """Parameters no gradient reached this step get `.grad = None` for the optimizer call, as in
+        the reference's loop (Adam skips them); returns them for `attach()` afterwards."""
+        unused = [p for p in self.params if p not in self._fired]
+        for p in unused:
+            p.grad = None
+        return unused
 
 
-def train_step(model, bucket, opt, loss_fn, inputs, clip=5.0, group=None):
-    """One data-parallel step: fwd, bwd, bucket all-reduce, clip, optimizer."""
-    opt.zero_grad(set_to_none=True)
+class DirectRccl:
+    """This package's own RCCL communicator over the ranks of a torch.distributed group, driven
+    through the C ABI (`lss_rccl_*`, `lss_allreduce_bucket` in include/lss_hip.h).  The unique id is
+    created on rank 0 and broadcast through the (already initialised) torch process group."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        from . import _native as N
+        self.N = N
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        uid = [N.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self.comm = N.rccl_comm_init(uid[0], world, rank)
+        self.world = world
+
+    def all_reduce_sum(self, t):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("all_reduce_sum: contiguous fp32 GPU tensor")
+        N = self.N
+        N.check(N.lib().lss_allreduce_bucket(self.comm, N.ptr(t), t.numel(), N.stream()), "lss_allreduce_bucket")
+
+    def close(self):
+        if self.comm is not None:
+            self.N.lib().lss_rccl_comm_destroy(self.comm)
+            self.comm = None
+
+
+def make_bucket(model_or_params, group=None, n_buckets=3, overlap=True):
+    params = model_or_params.parameters() if isinstance(model_or_params, torch.nn.Module) else model_or_params
+    bucket = GradBucket(params, n_buckets=n_buckets, group=group, overlap=overlap)
+    if os.environ.get("LSS_DP_DIRECT_RCCL") == "1" and bucket.flat.is_cuda and bucket._world() > 1:
+        bucket.use_direct_rccl(DirectRccl(group))
+    return bucket
+
+
+def train_step(model, bucket, opt, loss_fn, inputs, clip=5.0):
+    """One data-parallel step: fwd, bwd (bucket all-reduces start inside it), mean, clip, optimizer."""
+    bucket.zero()
     loss = loss_fn(model(*inputs))
     loss.backward()
-    bucket.all_reduce_mean(group)
-    torch.nn.utils.clip_grad_norm_(bucket.params, clip)
+    bucket.all_reduce_mean()
+    bucket.clip_grad_norm_(clip)
+    unused = bucket.hide_unused()
     opt.step()
+    if unused:
+        bucket.attach()
     return loss.detach()

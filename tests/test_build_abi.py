@@ -49,10 +49,34 @@ def test_argument_checks_without_gpu(built):
     assert L.lss_depthnet_softmax_fwd(one, one, one, 1, 100, 4, 4, 4, one, one, 0, None) == -2  # Cin % 64
 
 
-def test_exact_index_kernel_has_no_contracted_fma():
-    """geom_bucket.hip must be built with -ffp-contract=off."""
+def test_exact_index_kernel_has_no_contracted_fma(tmp_path):
+    """geom_bucket.hip must be built with -ffp-contract=off - and the ISA it then compiles to
+    must really hold no fused multiply-add in the two geometry -> voxel-id kernels (a contracted a*b+c rounds
+    once where torch-CPU rounds twice, and flips voxel ids)."""
+    import subprocess
     from lss2_multimodal_nu_amd import build_native
-    assert "-ffp-contract=off" in build_native.SOURCES["geom_bucket.hip"]
+    flags = build_native.SOURCES["geom_bucket.hip"]
+    assert "-ffp-contract=off" in flags
+    asm = tmp_path / "geom_bucket.s"
+    subprocess.check_call([build_native._hipcc(), "-S", "--cuda-device-only", "-o", str(asm),
+                           os.path.join(build_native.CSRC, "geom_bucket.hip")] + build_native.COMMON + flags,
+                          stderr=subprocess.DEVNULL)
+    text = asm.read_text()
+    # IEEE fp32 division (the reference divides by dx, src/model_BEV_TXT.py:92) expands to v_div_scale / v_rcp /
+    # FOUR v_fma + ONE v_fmac / v_div_fmas / v_div_fixup: those 5 fused ops per division ARE the correctly rounded
+    # quotient.  Any fused op beyond them would be a contracted a*b+c of the geometry arithmetic.
+    fused = re.compile(r"\bv_(pk_)?(fma|fmac|mac|mad)_(f32|legacy_f32)")
+    seen = 0
+    for name in ("points_to_voxels_kernel", "geom_to_voxels_kernel"):
+        m = re.search(r"^_ZN[^\n]*%s[^\n]*\n(.*?)s_endpgm" % name, text, flags=re.S | re.M)
+        assert m, name
+        body = m.group(1)
+        ndiv = len(re.findall(r"\bv_div_fmas_f32", body))
+        assert ndiv == 3, (name, ndiv)                                   # x, y, z quotients
+        assert "v_mul_f32" in body and "v_add_f32" in body, name         # the un-fused arithmetic is there
+        assert len(fused.findall(body)) == 5 * ndiv, (name, len(fused.findall(body)))
+        seen += 1
+    assert seen == 2
 
 
 def test_no_oracle_import_in_product():

@@ -56,8 +56,10 @@ def _worker(rank, world, port, out):
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     if rank == 0:
-        torch.save({"params": flat, "grads": bucket.flat.clone(), "equal_across_ranks":
-                    all(torch.equal(gathered[0], g) for g in gathered), "loss": loss}, out)
+        torch.save({"params": flat, "grads": torch.cat([p.grad.reshape(-1) for p in bucket.params]).clone(),
+                    "equal_across_ranks": all(torch.equal(gathered[0], g) for g in gathered), "loss": loss,
+                    "views": all(p.grad.data_ptr() == bucket.views[p].data_ptr() for p in bucket.params),
+                    "n_buckets": len(bucket.buckets)}, out)
     dist.destroy_process_group()
 
 
@@ -67,6 +69,7 @@ def test_two_rank_step_equals_single_process(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     got = torch.load(out)
     assert got["equal_across_ranks"], "ranks diverged after the step"
+    assert got["views"] and got["n_buckets"] == 3  # every p.grad is a slice of the flat buffer (no pack / unpack)
     # same direction as the single-process whole-batch gradient (weighted CE normalises by
     # the per-process sum of target weights, so magnitudes differ by that mix; the exact
     # equality check uses an unweighted mean loss below)
@@ -92,7 +95,9 @@ def test_mean_loss_gradients_match_exactly(tmp_path):
     with torch.enable_grad():
         m(x).pow(2).mean().backward()
     ref = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.requires_grad])
-    torch.testing.assert_close(got, ref, rtol=2e-4, atol=1e-6)
+    torch.testing.assert_close(got["grads"], ref, rtol=2e-4, atol=1e-6)
+    # every bucket's collective was started from inside backward (overlap), in completion order
+    assert got["in_backward"] == list(range(got["n_buckets"]))
 
 
 def _worker_mse(rank, world, port, out):
@@ -103,11 +108,17 @@ def _worker_mse(rank, world, port, out):
     x, _ = _data()
     lo, hi = dp.shard_range(x.shape[0], rank, world)
     bucket = dp.GradBucket(m.parameters())
+    launched = []
+    real_launch = bucket._launch
+    bucket._launch = lambda b: (launched.append(b), real_launch(b))[1]
+    bucket.zero()
     with torch.enable_grad():
         m(x[lo:hi]).pow(2).mean().backward()
+    in_backward = list(launched)  # all-reduces started by the backward hooks, before anyone asked for the mean
     bucket.all_reduce_mean()
     if rank == 0:
-        torch.save(bucket.flat.clone(), out)
+        torch.save({"grads": torch.cat([p.grad.reshape(-1) for p in bucket.params]).clone(),
+                    "in_backward": in_backward, "n_buckets": len(bucket.buckets)}, out)
     dist.destroy_process_group()
 
 
@@ -115,3 +126,33 @@ def test_shard_range():
     assert dp.shard_range(32, 3, 8) == (12, 16)
     with pytest.raises(ValueError):
         dp.shard_range(10, 0, 4)
+
+
+def test_bucket_views_clip_and_unused_parameters():
+    """Single process (no process group): p.grad are views of the flat buffer and survive a step; the
+    flat-buffer clip equals torch.nn.utils.clip_grad_norm_; parameters no gradient reached are hidden from the
+    optimizer like the reference's `grad is None` ones."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    unused = torch.nn.Linear(3, 3)
+    params = list(net.parameters()) + list(unused.parameters())
+    bucket = dp.GradBucket(params, n_buckets=2)
+    opt = torch.optim.Adam(bucket.params, lr=1e-2, weight_decay=1e-2)
+    x = torch.randn(5, 8)
+    w_unused = unused.weight.detach().clone()
+    for _ in range(2):
+        dp.train_step(net, bucket, opt, lambda y: (y * 100).pow(2).mean(), (x,), clip=5.0)
+        assert all(p.grad is bucket.views[p] for p in bucket.params)
+    assert torch.equal(unused.weight.detach(), w_unused)  # no gradient -> no Adam / weight-decay update
+    # clip value vs torch's
+    bucket.zero()
+    (net(x) * 100).pow(2).mean().backward()
+    ref = [p.grad.clone() for p in net.parameters()]
+    ref_params = [torch.nn.Parameter(torch.zeros_like(g)) for g in ref]
+    for rp, g in zip(ref_params, ref):
+        rp.grad = g.clone()
+    total_ref = torch.nn.utils.clip_grad_norm_(ref_params, 5.0)
+    total = bucket.clip_grad_norm_(5.0)
+    torch.testing.assert_close(total, total_ref, rtol=1e-5, atol=1e-6)
+    for p, rp in zip(net.parameters(), ref_params):
+        torch.testing.assert_close(p.grad, rp.grad, rtol=1e-5, atol=1e-7)

@@ -138,3 +138,27 @@ def test_sync_bn_two_ranks_equal_one_device_whole_batch(tmp_path):
     assert cos(got["grads"], ref_g) > 0.995 and rel(got["grads"], ref_g) < 0.1
     assert cos(got["gx"], xr.grad.cpu()) > 0.99
     assert rel(got["rm"], be.bn1.running_mean.detach().cpu()) < 1e-3  # global statistics in the running estimate
+
+
+def test_direct_rccl_binding_single_rank():
+    """`lss_allreduce_bucket` (include/lss_hip.h) on a one-rank RCCL communicator: the symbols resolve from
+    the librccl already loaded by PyTorch-ROCm, the communicator initialises on this GPU, and an in-place sum over
+    one rank returns the buffer unchanged, ordered on torch's current stream.  (More ranks need more GPUs than
+    this box has: RCCL refuses two ranks on one device; the N > 1 logic is covered on gloo.)"""
+    from lss2_multimodal_nu_amd import _native as N
+    assert N.rccl_version() >= 20000
+    uid = N.rccl_unique_id()
+    assert len(uid) == N.lib().lss_rccl_unique_id_bytes() == 128
+    torch.cuda.set_device(0)
+    comm = N.rccl_comm_init(uid, 1, 0)
+    try:
+        x = torch.randn(1 << 20, device="cuda")
+        ref = x.clone()
+        y = x * 2.0  # a kernel in flight on the stream the collective is ordered behind
+        N.check(N.lib().lss_allreduce_bucket(comm, N.ptr(y), y.numel(), N.stream()), "lss_allreduce_bucket")
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref * 2.0)
+        with pytest.raises(ValueError):
+            N.check(N.lib().lss_allreduce_bucket(comm, N.ptr(y), 0, N.stream()), "lss_allreduce_bucket")
+    finally:
+        N.check(N.lib().lss_rccl_comm_destroy(comm), "lss_rccl_comm_destroy")

@@ -341,14 +341,29 @@ CONVS = [
 ]
 
 
+def _q(t, dt):
+    """What the bf16 kernels actually consume: operands rounded to bf16 once (exactly representable in fp32).
+    The fp32 torch reference is evaluated on THESE values, so the remaining difference is fp32 summation
+    order + the single bf16 rounding of the output (<= 2^-8 relative) - and the tolerance can be that tight."""
+    return t if (dt == 0 or t is None) else t.bfloat16().float()
+
+
+# bf16 kernels vs the fp32 reference on bf16-rounded operands: half an ulp of the output rounding is 2^-8 =
+# 3.9e-3 of |value|; measured maxima (r02, gpurun_out/test_errors.txt) sit at 2.0e-3 .. 3.9e-3 of max|ref|.
+BF16_OUT_TOL = 6e-3
+# fused bilinear upsample: the interpolated operand is itself rounded to bf16 before the MFMA (one extra rounding
+# per input element); measured <= 4.5e-3
+BF16_UP_TOL = 1.2e-2
+
+
 @pytest.mark.parametrize("cfg", CONVS)
 @pytest.mark.parametrize("dt", [0, 1])
-def test_k8_conv_vs_torch(ops, cfg, dt):
+def test_k8_conv_vs_torch(ops, report, cfg, dt):
     B, H, W, Cx, Cout, k, stride, pad, relu, use_res, C2, up = cfg
     gen = torch.Generator().manual_seed(sum(cfg))
-    x = torch.randn(B, Cx, H, W, generator=gen)
-    x2 = torch.randn(B, C2, H * up, W * up, generator=gen) if C2 else None
-    w = torch.randn(Cout, Cx + C2, k, k, generator=gen) * ((Cx + C2) * k * k) ** -0.5
+    x = _q(torch.randn(B, Cx, H, W, generator=gen), dt)
+    x2 = _q(torch.randn(B, C2, H * up, W * up, generator=gen), dt) if C2 else None
+    w = _q(torch.randn(Cout, Cx + C2, k, k, generator=gen) * ((Cx + C2) * k * k) ** -0.5, dt)
     scale = torch.rand(Cout, generator=gen) + 0.5
     shift = torch.randn(Cout, generator=gen) * 0.1
     xin = x
@@ -358,7 +373,7 @@ def test_k8_conv_vs_torch(ops, cfg, dt):
         xin = torch.cat([x2, xin], 1)
     raw = torch.nn.functional.conv2d(xin, w, None, stride=stride, padding=pad)
     ref = raw * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
-    res = torch.randn(ref.shape, generator=gen) if use_res else None
+    res = _q(torch.randn(ref.shape, generator=gen), dt) if use_res else None
     if use_res:
         ref = ref + res
     if relu:
@@ -371,8 +386,10 @@ def test_k8_conv_vs_torch(ops, cfg, dt):
     y = ops.conv2d_nhwc(xg, wp, (k, k), stride, pad, scale.cuda(), shift.cuda(), resg, relu, x2g, up, stats, dt)
     out = ops.nhwc_to_nchw(y, dt).cpu()
     assert out.shape == ref.shape
-    tol = 2e-5 if dt == 0 else 2.5e-2
-    assert float((out - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-6
+    tol = 2e-5 if dt == 0 else (BF16_UP_TOL if up > 1 else BF16_OUT_TOL)
+    err = report("k8_conv_max_rel_dt%d_%s" % (dt, "x".join(str(int(c)) for c in cfg)),
+                 (out - ref).abs().max() / ref.abs().max())
+    assert err <= tol
     s = stats.cpu()
     np.testing.assert_allclose(s[:Cout].numpy(), raw.sum((0, 2, 3)).numpy(), rtol=tol * 4, atol=tol * 4 * float(raw.abs().sum((0, 2, 3)).max()))
     np.testing.assert_allclose(s[Cout:].numpy(), (raw ** 2).sum((0, 2, 3)).numpy(), rtol=max(tol * 4, 1e-4))
@@ -390,18 +407,18 @@ S2_CONVS = [  # B, H, W, Cin, Cout, k, relu, residual
 
 
 @pytest.mark.parametrize("cfg", S2_CONVS)
-def test_k8_stride2_conv_phase_plane_path(ops, cfg):
+def test_k8_stride2_conv_phase_plane_path(ops, report, cfg):
     """Stride-2 convs through the space-to-depth form of the LDS-tiled kernel."""
     B, H, W, Cin, Cout, k, relu, use_res = cfg
     pad = k // 2
     gen = torch.Generator().manual_seed(sum(cfg[:6]))
-    x = torch.randn(B, Cin, H, W, generator=gen)
-    w = torch.randn(Cout, Cin, k, k, generator=gen) * (Cin * k * k) ** -0.5
+    x = _q(torch.randn(B, Cin, H, W, generator=gen), 1)
+    w = _q(torch.randn(Cout, Cin, k, k, generator=gen) * (Cin * k * k) ** -0.5, 1)
     scale = torch.rand(Cout, generator=gen) + 0.5
     shift = torch.randn(Cout, generator=gen) * 0.1
     raw = torch.nn.functional.conv2d(x, w, None, stride=2, padding=pad)
     ref = raw * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
-    res = torch.randn(ref.shape, generator=gen) if use_res else None
+    res = _q(torch.randn(ref.shape, generator=gen), 1) if use_res else None
     if use_res:
         ref = ref + res
     if relu:
@@ -413,22 +430,24 @@ def test_k8_stride2_conv_phase_plane_path(ops, cfg):
     y = ops.conv2d_s2_nhwc(xg, wp, k, pad, scale.cuda(), shift.cuda(), resg, relu, stats)
     out = ops.nhwc_to_nchw(y, 1).cpu()
     assert out.shape == ref.shape
-    assert float((out - ref).abs().max()) <= 2.5e-2 * float(ref.abs().max()) + 1e-6
-    # and it agrees with the generic direct kernel on the same bf16 inputs to fp32-sum noise
+    assert report("k8_s2_max_rel_" + "x".join(str(int(c)) for c in cfg),
+                  (out - ref).abs().max() / ref.abs().max()) <= BF16_OUT_TOL
+    # and it agrees with the generic direct kernel on the same bf16 inputs to fp32-sum noise (one bf16 ulp
+    # where the two fp32 sums round to different neighbours)
     y0 = ops.conv2d_nhwc(xg, ops.pack_conv_weight(w.cuda(), 1), (k, k), 2, pad, scale.cuda(), shift.cuda(), resg, relu, dt=1)
-    assert float((y.float() - y0.float()).abs().max()) <= 1.6e-2 * float(ref.abs().max())
+    assert float((y.float() - y0.float()).abs().max()) <= 8e-3 * float(ref.abs().max())
     np.testing.assert_allclose(stats[:Cout].cpu().numpy(), raw.sum((0, 2, 3)).numpy(), rtol=0.1,
                                atol=0.1 * float(raw.abs().sum((0, 2, 3)).max()))
 
 
 @pytest.mark.parametrize("cfg", [(2, 12, 10, 256, 0, 2, 4), (1, 9, 16, 64, 0, 1, 3), (1, 5, 6, 128, 64, 4, 4)])
-def test_k8_conv_with_fused_head(ops, cfg):
+def test_k8_conv_with_fused_head(ops, report, cfg):
     """up2 of BevEncode in one launch: (upsample) + 3x3 conv + scale/shift + ReLU + 1x1 head -> NCHW fp32."""
     B, H, W, Cx, C2, up, n = cfg
     gen = torch.Generator().manual_seed(sum(cfg))
-    x = torch.randn(B, Cx, H, W, generator=gen)
-    x2 = torch.randn(B, C2, H * up, W * up, generator=gen) if C2 else None
-    w = torch.randn(128, Cx + C2, 3, 3, generator=gen) * ((Cx + C2) * 9) ** -0.5
+    x = _q(torch.randn(B, Cx, H, W, generator=gen), 1)
+    x2 = _q(torch.randn(B, C2, H * up, W * up, generator=gen), 1) if C2 else None
+    w = _q(torch.randn(128, Cx + C2, 3, 3, generator=gen) * ((Cx + C2) * 9) ** -0.5, 1)
     scale, shift = torch.rand(128, generator=gen) + 0.5, torch.randn(128, generator=gen) * 0.1
     hw, hb = torch.randn(n, 128, generator=gen) * 128 ** -0.5, torch.randn(n, generator=gen)
     xin = bo.upsample_bilinear_ac(x, up) if up > 1 else x
@@ -440,7 +459,10 @@ def test_k8_conv_with_fused_head(ops, cfg):
                                 shift.cuda(), hw.cuda(), hb.cuda(), x2=ops.nchw_to_nhwc(x2.cuda(), 1) if C2 else None,
                                 up=up).cpu()
     assert out.shape == ref.shape and out.is_contiguous()
-    assert float((out - ref).abs().max()) <= 2.5e-2 * float(ref.abs().max())
+    # the head sums 128 activations: with an MFMA head the activation is rounded to bf16 first (as the unfused
+    # two-launch path does), so the bound is the output-rounding one, not fp32 noise
+    assert report("k8_head_max_rel_" + "x".join(str(int(c)) for c in cfg),
+                  (out - ref).abs().max() / ref.abs().max()) <= (BF16_UP_TOL if up > 1 else BF16_OUT_TOL)
 
 
 @pytest.mark.parametrize("rt", ["1", "2"])
@@ -449,12 +471,12 @@ def test_k8_conv_tile_variants_agree(ops, rt, monkeypatch):
     monkeypatch.setenv("LSS_CONV_RT", rt)
     gen = torch.Generator().manual_seed(11)
     for (B, H, W, Cin, Cout) in ((2, 25, 25, 128, 256), (1, 37, 20, 64, 64), (1, 9, 50, 192, 130)):
-        x = torch.randn(B, Cin, H, W, generator=gen)
-        w = torch.randn(Cout, Cin, 3, 3, generator=gen) * (Cin * 9) ** -0.5
+        x = _q(torch.randn(B, Cin, H, W, generator=gen), 1)
+        w = _q(torch.randn(Cout, Cin, 3, 3, generator=gen) * (Cin * 9) ** -0.5, 1)
         ref = torch.nn.functional.conv2d(x, w, None, padding=1)
         y = ops.conv2d_nhwc(ops.nchw_to_nhwc(x.cuda(), 1), ops.pack_conv_weight(w.cuda(), 1), (3, 3), 1, 1, dt=1)
         out = ops.nhwc_to_nchw(y, 1).cpu()
-        assert float((out - ref).abs().max()) <= 2.5e-2 * float(ref.abs().max())
+        assert float((out - ref).abs().max()) <= BF16_OUT_TOL * float(ref.abs().max())
 
 
 def test_bad_arguments_raise(ops):

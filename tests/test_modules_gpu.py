@@ -14,6 +14,10 @@ from oracle import lss_oracle as lo  # noqa: E402
 GRID = dict(xbound=[-50.0, 50.0, 0.5], ybound=[-50.0, 50.0, 0.5], zbound=[-10.0, 10.0, 20.0],
             dbound=[4.0, 45.0, 1.0])
 AUG = {"final_dim": (128, 352), "Ncams": 6}
+# bf16 conv path (bf16 operands, fp32 accumulation, 19 layers): rel-L2 of the BevEncode output against the fp32
+# oracle.  Measured on MI355X: 3.7e-4 ... 1.1e-3 depending on the weights (gpurun_out/test_errors.txt, r02);
+# the bound is ~3x the largest observed value, so a regression of 1e-2 fails.
+BF16_TOL = 4e-3
 
 
 def randomize_bn(m, seed=3):
@@ -68,8 +72,8 @@ def test_get_voxels_vs_reference(model, golden):
     assert int((np.abs(out).sum(1) > 0).sum()) == int(g["n_occupied"])
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 4e-2)])
-def test_lss_forward_vs_oracle(golden, precision, tol):
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", BF16_TOL)])
+def test_lss_forward_vs_oracle(golden, report, precision, tol):
     torch.manual_seed(1)
     B = 2
     m = L.compile_model_lss(B, GRID, AUG, 4, precision=precision)
@@ -84,12 +88,13 @@ def test_lss_forward_vs_oracle(golden, precision, tol):
     grid = lo.lift_splat_torch(x, sd["camencode.depthnet.weight"], sd["camencode.depthnet.bias"], sd["frustum"],
                                *calib, sd["dx"], sd["bx"], sd["nx"], B, 41, 64)
     ref = bo.bev_encode(grid, {k[len("bevencode."):]: v for k, v in sd.items() if k.startswith("bevencode.")})
-    err = float((out.cpu() - ref).norm() / ref.norm())
+    err = report("lss_forward_rel_l2_" + precision, (out.cpu() - ref).norm() / ref.norm())
+    emax = report("lss_forward_max_rel_" + precision, (out.cpu() - ref).abs().max() / ref.abs().max())
     assert err < tol, err
-    assert float((out.cpu() - ref).abs().max()) < 5 * tol * float(ref.abs().max())
+    assert emax < 5 * tol, emax
 
 
-def test_lss_forward_hires_config5_shapes():
+def test_lss_forward_hires_config5_shapes(report):
     """BASELINE config 5 shapes per GPU: 6 x (16x44) features, D = 60, 400 x 400 BEV, batch 2."""
     grid = dict(xbound=[-50.0, 50.0, 0.25], ybound=[-50.0, 50.0, 0.25], zbound=[-10.0, 10.0, 20.0],
                 dbound=[1.0, 61.0, 1.0])
@@ -108,9 +113,9 @@ def test_lss_forward_hires_config5_shapes():
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
     ref_grid = lo.lift_splat_torch(x, sd["camencode.depthnet.weight"], sd["camencode.depthnet.bias"], sd["frustum"],
                                    *calib, sd["dx"], sd["bx"], sd["nx"], B, 60, 64)
-    assert float((grid_t.cpu() - ref_grid).norm() / ref_grid.norm()) < 1e-3
+    assert report("hires_grid_rel_l2", (grid_t.cpu() - ref_grid).norm() / ref_grid.norm()) < 1e-3
     ref = bo.bev_encode(ref_grid, {k[len("bevencode."):]: v for k, v in sd.items() if k.startswith("bevencode.")})
-    assert float((out.cpu() - ref).norm() / ref.norm()) < 4e-2
+    assert report("hires_out_rel_l2_bf16", (out.cpu() - ref).norm() / ref.norm()) < BF16_TOL
 
 
 def test_plan_replay_equals_eager(monkeypatch):
@@ -137,11 +142,31 @@ def test_plan_replay_equals_eager(monkeypatch):
         m.bevencode.invalidate_plan()
         shifted = m(xs[0], *calibs[0])
         assert torch.allclose(shifted, eager[0] + 1.0, atol=1e-5)
-        # load_state_dict invalidates by itself
+        # load_state_dict on the PARENT model (never reaches BevEncode.load_state_dict): the plan holds packed
+        # copies of the 3x3 weights and folded BN scale/shift, so these checks fail on a stale plan
         sd = {k: v.clone() for k, v in m.state_dict().items()}
         sd["bevencode.up2.4.bias"] -= 1.0
         m.load_state_dict(sd)
         assert torch.allclose(m(xs[0], *calibs[0]), eager[0], atol=1e-5)
+        for key in ("bevencode.layer1.0.conv1.weight", "bevencode.up1.conv.1.weight",
+                    "bevencode.layer2.0.downsample.0.weight", "bevencode.layer3.0.downsample.1.running_var"):
+            sd2 = {k: v.clone() for k, v in m.state_dict().items()}
+            sd2[key] = sd2[key] * 1.5
+            m.load_state_dict(sd2)
+            replay = m(xs[0], *calibs[0]).clone()
+            monkeypatch.setenv("LSS_NO_PLAN", "1")
+            fresh = m(xs[0], *calibs[0]).clone()
+            monkeypatch.delenv("LSS_NO_PLAN")
+            assert torch.equal(replay, fresh), key
+            assert not torch.equal(replay, eager[0]), key
+            m.load_state_dict(sd)
+        # the same through an in-place edit with no invalidation call at all
+        m.bevencode.layer2[1].conv2.weight.mul_(0.5)
+        replay = m(xs[0], *calibs[0]).clone()
+        monkeypatch.setenv("LSS_NO_PLAN", "1")
+        fresh = m(xs[0], *calibs[0]).clone()
+        monkeypatch.delenv("LSS_NO_PLAN")
+        assert torch.equal(replay, fresh)
 
 
 def test_bevencode_and_up_modules_vs_oracle(golden):
@@ -165,8 +190,8 @@ def test_bevencode_and_up_modules_vs_oracle(golden):
         up.cuda().eval()(torch.from_numpy(g["x1"]).cuda(), torch.from_numpy(g["x2"]).cuda())
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 3e-2)])
-def test_encoder_up1_from_trunk_endpoints(prec, tol):
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 1.5e-2)])
+def test_encoder_up1_from_trunk_endpoints(report, prec, tol):
     """Encoder.up1 = Up(448+160, 512) on EfficientNet-B4 endpoint shapes (160 skip channels
     are not a multiple of the 64-channel K block)."""
     torch.manual_seed(5)
@@ -182,7 +207,7 @@ def test_encoder_up1_from_trunk_endpoints(prec, tol):
     sd = {k: v.cpu() for k, v in enc.state_dict().items()}
     ref = bo.up_block(r5, r4, sd, "up1", 2)
     assert y.shape == (6, 512, 8, 22) and torch.equal(y, y2)
-    assert float((y.cpu() - ref).abs().max()) <= tol * float(ref.abs().max())
+    assert report("encoder_up1_max_rel_" + prec, (y.cpu() - ref).abs().max() / ref.abs().max()) <= tol
     with pytest.raises(RuntimeError):
         enc(torch.zeros(1, 6, 3, 128, 352).cuda())
 
@@ -281,8 +306,9 @@ def test_forward_with_loader_side_calibration_pack_is_bitwise_identical(model, g
     change a single bit of the result (exact-index contract)."""
     g = golden("g3_train_b1_s0")
     calib = [torch.from_numpy(g[k]) for k in ("rots", "trans", "intrins", "post_rots", "post_trans")]
-    pack = L.prepare_calibration(*calib)
+    pack = L.prepare_calibration(*calib, pin=True)
     assert pack.buffer.is_pinned() and pack.shape == (1, 6)
+    assert not L.prepare_calibration(*calib).buffer.is_pinned()  # default: safe inside DataLoader workers
     torch.manual_seed(11)
     x = torch.randn(6, 512, 8, 22).cuda()
     with torch.no_grad():
@@ -359,12 +385,89 @@ def test_weighted_cross_entropy_fused_vs_torch(C):
     w = (torch.rand(C, generator=g) * 9 + 1).cuda()
     loss = weighted_cross_entropy(x, t, w)
     (loss * 1.7).backward()
-    xr = x.detach().clone().requires_grad_(True)
-    ref = torch.nn.functional.cross_entropy(xr, t, weight=w)
+    # reference value: the same loss evaluated on the CPU in fp64 (ref src/tools.py:221-231 is
+    # nn.CrossEntropyLoss(weight=...)), not another GPU kernel
+    xr = x.detach().cpu().double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, t.cpu(), weight=w.cpu().double())
     (ref * 1.7).backward()
     assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
-    assert float((x.grad - xr.grad).abs().max()) <= 1e-5 * float(xr.grad.abs().max())
+    assert float((x.grad.cpu().double() - xr.grad).abs().max()) <= 1e-5 * float(xr.grad.abs().max())
     if C == 4:
         sl = SimpleLoss().cuda()
-        ref4 = torch.nn.functional.cross_entropy(xr.detach(), t, weight=torch.tensor([1.0, 10.0, 5.0, 10.0]).cuda())
+        ref4 = torch.nn.functional.cross_entropy(xr.detach(), t.cpu(), weight=torch.tensor([1.0, 10.0, 5.0, 10.0]).double())
         assert abs(float(sl(x.detach(), t)) - float(ref4)) <= 1e-5 * abs(float(ref4))
+
+
+@pytest.mark.parametrize("variant", ["txt", "onlybev"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_bev_txt_forward_on_gpu(report, variant, precision):
+    """`BEV_TXT.forward` (ref src/model_BEV_TXT.py:278-334) and the only-BEV variant (ref
+    src/model_baseline.py:274-290) executed on the GPU: the BEV map against the CPU oracle, the crop
+    [:, :, 60:140, 56:144] + BevPost + heads against the SAME heads evaluated by CPU torch on the GPU's BEV map
+    (the heads are stock PyTorch on ROCm; the CPU TXT half is pinned to the reference in test_modules_cpu.py)."""
+    import copy
+    torch.manual_seed(7)
+    B = 2
+    make = L.compile_model_bevtxt if variant == "txt" else L.compile_model_onlybev
+    m = make(B, GRID, AUG, 4, precision=precision)
+    randomize_bn(m)
+    m.eval()
+    cpu = copy.deepcopy(m)
+    m = m.cuda()
+    calib = lo.synthetic_rig(B, train_aug=True, seed=9)
+    x = torch.randn(B * 6, 512, 8, 22)
+    with torch.no_grad():
+        bev, act, desc = m(x.cuda(), *calib)
+    assert bev.shape == (B, 4, 200, 200) and act.shape == (B, 4) and desc.shape == (B, 8)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    grid = lo.lift_splat_torch(x, sd["camencode.depthnet.weight"], sd["camencode.depthnet.bias"], sd["frustum"],
+                               *calib, sd["dx"], sd["bx"], sd["nx"], B, 41, 64)
+    ref = bo.bev_encode(grid, {k[len("bevencode."):]: v for k, v in sd.items() if k.startswith("bevencode.")})
+    tol = 2e-4 if precision == "fp32" else BF16_TOL
+    assert report("bevtxt_%s_bev_rel_l2_%s" % (variant, precision), (bev.cpu() - ref).norm() / ref.norm()) < tol
+    # TXT half on the CPU from the GPU's own BEV map
+    bev_cpu = bev.cpu()
+    cpu._bev = lambda *a: bev_cpu
+    with torch.no_grad():
+        _, act_ref, desc_ref = cpu(x, *calib)
+        crop = cpu.bevpost(bev_cpu[:, :, 60:140, 56:144])
+    assert crop.shape == (B, 8, 8, 22)
+    np.testing.assert_allclose(act.cpu().numpy(), act_ref.numpy(), rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(desc.cpu().numpy(), desc_ref.numpy(), rtol=2e-3, atol=2e-4)
+    # and a differentiable training step through the whole model (ref train.py:52-65 with MultiLoss)
+    m.train()
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+    bev_t, act_t, desc_t = m(x.cuda(), *calib)
+    loss = L.MultiLoss(bev_t, act_t, desc_t, torch.randint(0, 4, (B, 200, 200)).cuda(),
+                       torch.rand(B, 4).round().cuda(), torch.rand(B, 8).round().cuda())
+    loss.backward()
+    opt.step()
+    assert torch.isfinite(loss)
+    if variant == "onlybev":  # heads -> BEV map -> BevEncode: the head loss alone reaches the conv weights
+        m.zero_grad()
+        _, a2, d2 = m(x.cuda(), *calib)
+        (a2.sum() + d2.sum()).backward()
+        assert float(m.bevencode.up2[4].weight.grad.abs().sum()) > 0
+
+
+def test_histogram_guard_rezeroes_the_workspace_after_a_failed_call(model, golden):
+    """an exception between K3 (histogram) and K4 (counts back to zero) must not poison the cached
+    workspace: the next good call gives the bits of a fresh model."""
+    g = golden("g3_train_b1_s0")
+    calib = [torch.from_numpy(g[k]) for k in ("rots", "trans", "intrins", "post_rots", "post_trans")]
+    torch.manual_seed(13)
+    x = torch.randn(6, 512, 8, 22).cuda()
+    with torch.no_grad():
+        good = model.get_voxels(x, *calib).clone()
+    xg = x.clone().requires_grad_(True)
+    w = model.camencode.depthnet.weight
+    try:
+        model.camencode.depthnet.weight = torch.nn.Parameter(w.detach()[:, :100].clone())  # wrong Cin: checks raise
+        with pytest.raises(ValueError):
+            model.get_voxels(xg, *calib)  # autograd path: K3 has already run when the operand check fires
+    finally:
+        model.camencode.depthnet.weight = w
+    for ws in model._ws.values():
+        assert int(ws.vox_count.abs().sum()) == 0 and int(ws.cursor.abs().sum()) == 0
+    with torch.no_grad():
+        assert torch.equal(model.get_voxels(x, *calib), good)

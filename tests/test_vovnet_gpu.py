@@ -22,11 +22,27 @@ def t(a):
     return torch.from_numpy(np.asarray(a))
 
 
+_REPORT = [None, "", 0]
+
+
+@pytest.fixture(autouse=True)
+def _error_log(report, request):
+    """Every rel() of a test lands in gpurun_out/test_errors.txt (tolerances are kept at a small multiple of it)."""
+    _REPORT[:] = [report, request.node.name, 0]
+    yield
+    _REPORT[0] = None
+
+
 def rel(a, b):
     a = a.detach().float().cpu().numpy().astype(np.float64) if torch.is_tensor(a) else np.asarray(a, np.float64)
     b = b.detach().float().cpu().numpy().astype(np.float64) if torch.is_tensor(b) else np.asarray(b, np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
-    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30), np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+    mx, l2 = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30), np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+    if _REPORT[0] is not None:
+        _REPORT[0]("%s#%d_max" % (_REPORT[1], _REPORT[2]), mx)
+        _REPORT[0]("%s#%d_l2" % (_REPORT[1], _REPORT[2]), l2)
+        _REPORT[2] += 1
+    return mx, l2
 
 
 def load(module, shapes, seed):
@@ -353,3 +369,48 @@ def test_vovnet_model_forward_smoke():
     assert seg.shape == (B, 4, 200, 200) and act.shape == (B, 4) and desc.shape == (B, 8)
     seg2, act2, desc2 = m(feats, *calib)  # grad enabled: torch ops for the heads/encoder, HIP splat
     assert rel(seg, seg2.detach())[1] <= 1e-3 and rel(act, act2.detach())[0] <= 1e-3
+
+
+def test_vovnet_config4_batch8():
+    """BASELINE configs[3] at its stated batch: batch 8, 6 cameras 8x22, 768/1024-channel trunk maps, C = 128,
+    200 x 200, bf16 conv path.  (i) lift-splat of all 8 samples against the CPU oracle; (ii) every sample of the
+    batch-8 run equals the same sample run alone at batch 1 (the path shards by sample: SURVEY.md 8e) to bf16
+    tile-order noise; (iii) BEV encoder (transformer + seg head) of samples 0 and 7 against the CPU oracle."""
+    B = 8
+    conf = dict(final_dim=(128, 352), Ncams=6, cams=list("abcdef"))
+    torch.manual_seed(4)
+    dsd = vo.seeded_state(vo.multiscale_depthnet_shapes(), 41)
+    csd = vo.seeded_state(vo.camencode_v2_shapes(), 42)
+    esd = vo.seeded_state(vo.bev_encoder_transformer_shapes(128, 4), 43)
+
+    def build(bsz):
+        m = L.compile_model_vovnet_transformer(bsz, GRID, conf, 4, lss_version="v2", precision="bf16")
+        m.depth_net.load_state_dict(dsd)
+        m.cam_encode.load_state_dict(csd)
+        m.bev_encoder.load_state_dict(esd)
+        return m.cuda().eval()
+
+    m8, m1 = build(B), build(1)
+    gen = np.random.RandomState(8)
+    c3 = t(gen.randn(B * 6, 768, 8, 22).astype(np.float32))
+    c4 = t(gen.randn(B * 6, 1024, 4, 11).astype(np.float32))
+    calib = lo.synthetic_rig(B, 6, train_aug=True, seed=11)
+    with torch.no_grad():
+        grid8 = m8.get_voxels(c3.cuda(), c4.cuda(), *calib)
+        seg8, act8, desc8 = m8({"c3": c3.cuda(), "c4": c4.cuda()}, *calib)
+    assert grid8.shape == (B, 128, 200, 200) and seg8.shape == (B, 4, 200, 200)
+    assert act8.shape == (B, 4) and desc8.shape == (B, 8)
+    dx, bx, nx = lo.gen_dx_bx(GRID["xbound"], GRID["ybound"], GRID["zbound"])
+    ref, _ = vo.vovnet_lift_splat(c3, c4, dsd, csd, "v2", m8.frustum.cpu(), *calib, dx, bx, nx, B)
+    mx, l2 = rel(grid8, ref)
+    assert l2 <= 1e-2 and mx <= 2e-2, (mx, l2)
+    for i in (0, 3, 7):
+        ci = [c[i:i + 1] for c in calib]
+        with torch.no_grad():
+            g1 = m1.get_voxels(c3[6 * i:6 * i + 6].cuda(), c4[6 * i:6 * i + 6].cuda(), *ci)
+            s1, _, _ = m1({"c3": c3[6 * i:6 * i + 6].cuda(), "c4": c4[6 * i:6 * i + 6].cuda()}, *ci)
+        assert rel(g1[0], grid8[i])[1] <= 1e-5      # fp32 splat: the same sums, sample by sample
+        assert rel(s1[0], seg8[i])[1] <= 5e-3       # bf16 encoder: tile shapes are chosen from the grid size
+    for i in (0, 7):
+        seg_ref, _ = vo.bev_encoder_transformer(ref[i:i + 1], esd)
+        assert rel(seg8[i:i + 1], seg_ref)[1] <= 2e-2
