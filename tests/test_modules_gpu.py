@@ -14,10 +14,11 @@ from oracle import lss_oracle as lo  # noqa: E402
 GRID = dict(xbound=[-50.0, 50.0, 0.5], ybound=[-50.0, 50.0, 0.5], zbound=[-10.0, 10.0, 20.0],
             dbound=[4.0, 45.0, 1.0])
 AUG = {"final_dim": (128, 352), "Ncams": 6}
-# bf16 conv path (bf16 operands, fp32 accumulation, 19 layers): rel-L2 of the BevEncode output against the fp32
-# oracle.  Measured on MI355X: 3.7e-4 ... 1.1e-3 depending on the weights (gpurun_out/test_errors.txt, r02);
-# the bound is ~3x the largest observed value, so a regression of 1e-2 fails.
-BF16_TOL = 4e-3
+# bf16 conv path (bf16 operands AND bf16 activations between the 19 layers, fp32 accumulation) against the fp32
+# oracle, whole BevEncode: measured rel-L2 on MI355X is 3.7e-4 (smoke weights) ... 6.3e-3 (these tests' randomised
+# BatchNorm; max-abs 1.3e-2 of max|ref|) - gpurun_out/test_errors.txt, r02.  The bound is 3x the largest observed
+# value (r01 allowed 4e-2 / 2e-1).  Single kernels are held to the bf16 output-rounding bound in test_kernels_gpu.py.
+BF16_TOL = 2e-2
 
 
 def randomize_bn(m, seed=3):
@@ -91,7 +92,7 @@ def test_lss_forward_vs_oracle(golden, report, precision, tol):
     err = report("lss_forward_rel_l2_" + precision, (out.cpu() - ref).norm() / ref.norm())
     emax = report("lss_forward_max_rel_" + precision, (out.cpu() - ref).abs().max() / ref.abs().max())
     assert err < tol, err
-    assert emax < 5 * tol, emax
+    assert emax < 2 * tol, emax
 
 
 def test_lss_forward_hires_config5_shapes(report):
