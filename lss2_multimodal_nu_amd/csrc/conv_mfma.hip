@@ -56,6 +56,7 @@ struct ConvArgs {
   const float* head_b;
   float* head_out;
   int head_n;
+  int head_valu;  // A/B switch: the fused head's VALU / DPP form instead of the MFMA form
   // diagnostics (tools/conv_phase_stamps.py): 8 x 100-MHz s_memrealtime stamps per workgroup, or null
   unsigned long long* stamps;
   int src_lds;  // MODE 1, KC = 32: the low-res source patch of a chunk is staged in LDS (see SRC below)
@@ -336,7 +337,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // RT = 32-pixel MFMA row tiles per wave (2: 4 image rows x 64 channels per wave, the
 // throughput shape; 1: 2 image rows, half the work per workgroup - used when the RT = 2
 // grid would leave CUs idle, where the per-workgroup critical path is what counts).
-template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64, int KSP = 1>
+// HEAD: the epilogue reduces the fused 1x1 head instead of storing the activation (its own instantiation: the
+// head and the store path each keep only their own operands live - the store path's residual prefetch and
+// the head's operand fragments together overflowed the 168-register budget of the KC = 32 kernels).
+template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64, int KSP = 1, bool HEAD = false>
 __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void conv_lds_kernel(ConvArgs a, int tilesX,
                                                                                              int tilesY) {
   // KSP = 2: intra-workgroup split-K for grids that cannot fill the chip (layer2/layer3: 112-208
@@ -767,10 +771,10 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
   const int ystep = a.Wo * ycw, rstep = a.Wo * a.Cout;       // elements per image row
   // residual rows: issued BEFORE the accumulators are staged, so the loads fly during the LDS
   // write / barrier / read-back instead of stalling the store loop
-  uint4 rres[EPH * EPJ];
+  uint4 rres[HEAD ? 1 : EPH * EPJ];
   const unsigned short* res = reinterpret_cast<const unsigned short*>(a.residual);
-  const bool res_vec = res != nullptr && !a.head_out && col_ok && (a.Cout & 7) == 0 && co + 8 <= a.Cout;
-  {
+  const bool res_vec = !HEAD && res != nullptr && col_ok && (a.Cout & 7) == 0 && co + 8 <= a.Cout;
+  if (!HEAD) {
     const unsigned short* rb = res + pixb * a.Cout + co;
 #pragma unroll
     for (int it = 0; it < EPH * EPJ; ++it) {
@@ -801,7 +805,7 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
             ost[pc * OLD + ct * 32] = acc[rt][ct][i] * sc + sh;
           }
       }
-      if (a.stats) {
+      if (!HEAD && a.stats) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
           const int cs = n0 + wc * 64 + ct * 32 + r;
@@ -832,9 +836,71 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
     if (half == 0) stamp(3);
     if (grp != 0) {
       // second K-split group: its sums were handed over above; it only keeps the barriers company
-    } else if (a.head_out) {
-      // fused 1x1 head: the CG = BN / 8 lanes that hold the channels of one pixel reduce their partial
-      // dot products with shuffles; the activation itself is never stored
+    } else if (HEAD && a.head_n <= 16 && !a.head_valu) {
+      // Fused 1x1 head ON THE MATRIX PIPE (ref src/modules.py:115, up2[4]): per image row of the staged tile one
+      // 16 x 16 x BN product  out[pixel][k] = sum_c relu(act[pixel][c]) * head_w[k][c]  on v_mfma_f32_16x16x32_bf16.
+      // Both operands are split into bf16 hi + lo parts (x = hi + lo to 16 significant bits) and the three
+      // products hi*hi, hi*lo, lo*hi are accumulated in fp32, so the result keeps the accuracy of the fp32
+      // head it replaces (the dropped lo*lo term is 2^-16 relative) while the VALU work per pixel falls from
+      // ~60 FMA / DPP instructions to ~12 conversions.  A: lane (r = pixel, q) <- 8 consecutive channels of the
+      // fp32 tile in LDS (2 ds_read_b128); B: lane (k = lane & 15, q) <- 8 consecutive weights of class k from
+      // global (L1-resident: 2 KiB); D: lane (k, q) holds pixels 4q..4q+3 of the row = ONE 16-B NCHW store.
+      typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+      const int hr = lane & 15, hq = lane >> 4;
+      for (int row = wave; row < HROWS; row += 4) {
+        const int oy = oy0 + half * HROWS + row;
+        f32x4_t hacc = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = otile + (row * 16 + hr) * OLD + hq * 8;
+        const float* wrow = a.head_w + (size_t)min(hr, a.head_n - 1) * BN + hq * 8;
+        // rolled: one k-step's 16 operand floats live at a time (the other half-tile's waves still hold their
+        // 64 accumulator registers here, and the 168-register budget of three workgroups per CU is what counts)
+#pragma unroll 1
+        for (int s = 0; s < BN / 32; ++s) {
+          bf16x8 xh, xl, wh, wl;
+          {
+            f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow + s * 32);
+            f32x4 w1 = *reinterpret_cast<const f32x4*>(wrow + s * 32 + 4);
+            if (hr >= a.head_n) { w0 = (f32x4){0.f, 0.f, 0.f, 0.f}; w1 = w0; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float wv = j < 4 ? w0[j & 3] : w1[j & 3];
+              const unsigned short whi = lss_f2bf(wv);
+              wh[j] = (short)whi;
+              wl[j] = (short)lss_f2bf(wv - lss_bf2f(whi));
+            }
+          }
+          {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(arow + s * 32);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(arow + s * 32 + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float xv = j < 4 ? x0[j & 3] : x1[j & 3];
+              if (a.relu) xv = fmaxf(xv, 0.f);
+              const unsigned short xhi = lss_f2bf(xv);
+              xh[j] = (short)xhi;
+              xl[j] = (short)lss_f2bf(xv - lss_bf2f(xhi));
+            }
+          }
+          hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh, hacc, 0, 0, 0);
+          hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl, hacc, 0, 0, 0);
+          hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wh, hacc, 0, 0, 0);
+        }
+        if (hr < a.head_n && oy < a.Ho) {
+          const float hb = a.head_b[hr];
+          float* op = a.head_out + (((size_t)b * a.head_n + hr) * a.Ho + oy) * a.Wo + ox0 + hq * 4;
+          if ((a.Wo & 3) == 0 && ox0 + hq * 4 + 4 <= a.Wo) {
+            *reinterpret_cast<f32x4_t*>(op) = (f32x4_t){hacc[0] + hb, hacc[1] + hb, hacc[2] + hb, hacc[3] + hb};
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (ox0 + hq * 4 + i < a.Wo) op[i] = hacc[i] + hb;
+          }
+        }
+      }
+    } else if (HEAD) {
+      // fused 1x1 head, VALU form (more than 16 classes, or LSS_CONV_HEAD_VALU=1 for A/B): the CG = BN / 8 lanes
+      // that hold the channels of one pixel reduce their partial dot products with DPP row operations; the
+      // activation itself is never stored
       {
         for (int e = tid; e < HROWS * 16 * CG; e += 256) {
           const int pl = e / CG, hc8 = e % CG;
@@ -1115,7 +1181,7 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   a.y2 = nullptr; a.split = 0; a.relu_n = a.Cout;
   const bool head_major = (relu & LSS_OUT_HEAD_MAJOR32) != 0;
   if (a.relu == 3 || (relu & ~(3 | LSS_OUT_F32 | LSS_OUT_HEAD_MAJOR32)) != 0) return LSS_E_LAYOUT;
-  a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0;
+  a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0; a.head_valu = 0;
   a.ry = a.Hin > 1 ? (float)(H - 1) / (float)(a.Hin - 1) : 0.f;
   a.rx = a.Win > 1 ? (float)(W - 1) / (float)(a.Win - 1) : 0.f;
   const bool fused = (up > 1) || (C2 > 0);
@@ -1178,7 +1244,7 @@ static int conv2d_s2_impl(const void* x, const void* w_s2d, const float* scale, 
   a.wt = (getenv("LSS_CONV_WT") == nullptr || atoi(getenv("LSS_CONV_WT")) != 0) &&
          (unsigned long long)a.M * a.Cout * 2 < (1ULL << 31);
   a.y2 = y2; a.split = split; a.relu_n = y2 ? relu_n : a.Cout;
-  a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0;
+  a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0; a.head_valu = 0;
   a.ry = a.rx = 0.f;
   hipStream_t st = lss_stream(stream);
   if (K == 7) launch_conv_lds<2, 4, 4, 2>(a, st);
@@ -1242,6 +1308,7 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
          (unsigned long long)a.M * a.Cout * 2 < (1ULL << 31);
   a.y2 = nullptr; a.split = 0; a.relu_n = a.Cout;
   a.head_w = head_w; a.head_b = head_b; a.head_out = out; a.head_n = head_n;
+  a.head_valu = getenv("LSS_CONV_HEAD_VALU") != nullptr && atoi(getenv("LSS_CONV_HEAD_VALU")) != 0;
   a.ry = a.Hin > 1 ? (float)(H - 1) / (float)(a.Hin - 1) : 0.f;
   a.rx = a.Win > 1 ? (float)(W - 1) / (float)(a.Win - 1) : 0.f;
   const bool fused = (up > 1) || (C2 > 0);
@@ -1253,14 +1320,14 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
   if (const char* e = getenv("LSS_CONV_KC")) kc32 = kc32 && atoi(e) == 32;
   if (fused && kc32) {
     a.src_lds = conv_src_lds_ok(a);
-    hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1, 32>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1, 32, 1, true>), g, dim3(256), 0, st, a, tilesX, tilesY);
   }
   else if (fused)
-    hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1, 64, 1, true>), g, dim3(256), 0, st, a, tilesX, tilesY);
   else if (Cout == 64)
-    hipLaunchKernelGGL((conv_lds_kernel<2, 64, 0, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    hipLaunchKernelGGL((conv_lds_kernel<2, 64, 0, 3, 3, 1, 64, 1, true>), g, dim3(256), 0, st, a, tilesX, tilesY);
   else
-    hipLaunchKernelGGL((conv_lds_kernel<2, 128, 0, 3, 3, 1>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    hipLaunchKernelGGL((conv_lds_kernel<2, 128, 0, 3, 3, 1, 64, 1, true>), g, dim3(256), 0, st, a, tilesX, tilesY);
   return lss_launch_status();
 }
 

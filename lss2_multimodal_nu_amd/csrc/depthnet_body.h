@@ -15,7 +15,7 @@ __device__ __forceinline__ void depthnet_epilogue(const f32x4 (&acc)[NT], float*
                                                   const float* __restrict__ bias_c, int feat_row0,
                                                   bool softmax, int bn, int pix0, int HW, int D,
                                                   int C, float* __restrict__ depth,
-                                                  float* __restrict__ feat) {
+                                                  float* __restrict__ feat, float* wg_absmax = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, j = lane >> 4;
   // logit rows: depth bins at [0, D), context channels at [feat_row0, feat_row0 + C)
@@ -56,9 +56,24 @@ __device__ __forceinline__ void depthnet_epilogue(const f32x4 (&acc)[NT], float*
   __syncthreads();
 
   // context features: feat[(bn*HW + pix)*C + c] = logit[D + c][pix]
+  float amax = 0.f;
   for (int e = tid; e < PIX * C; e += 256) {
     const int p = e / C, c = e % C;
-    if (pix0 + p < HW) feat[((size_t)bn * HW + pix0 + p) * C + c] = logit[(feat_row0 + c) * LDS_LD + p];
+    if (pix0 + p < HW) {
+      const float v = logit[(feat_row0 + c) * LDS_LD + p];
+      feat[((size_t)bn * HW + pix0 + p) * C + c] = v;
+      amax = fmaxf(amax, fabsf(v));  // fmaxf drops a NaN operand: a NaN feature does not poison the scale
+    }
+  }
+  if (wg_absmax != nullptr) {
+    // max |feature| of this workgroup (the region splat sizes its fixed-point accumulator from the maximum over all
+    // workgroups): one plain store per workgroup into its own slot - no atomics, nothing to reset between calls.
+    // `part` is free again (every thread passed the barrier above after its last read of it).
+    amax = lss_wave_max(amax);
+    if (lane == 0) part[wave] = amax;
+    __syncthreads();
+    if (tid == 0) *wg_absmax = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    __syncthreads();
   }
   if (!softmax) {  // raw logits (a later kernel fuses them, ref MultiScaleDepthNet)
     for (int e = tid; e < D * PIX; e += 256) {
@@ -106,7 +121,7 @@ template <int NT>
 __device__ __forceinline__ void depthnet_softmax_f32_body(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     int Cin, int HW, int D, int C, float* __restrict__ depth, float* __restrict__ feat, int tile_x, int bn,
-    float* lds) {
+    float* lds, float* wg_absmax = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, j = lane >> 4;
   const int pix0 = tile_x * PIX;
@@ -156,7 +171,7 @@ __device__ __forceinline__ void depthnet_softmax_f32_body(
   }
   if (i < nblk) mma_block(xs0, wa0);  // odd number of blocks: the last one is already loaded
 
-  depthnet_epilogue<NT>(acc, lds, bias, bias + D, D, true, bn, pix0, HW, D, C, depth, feat);
+  depthnet_epilogue<NT>(acc, lds, bias, bias + D, D, true, bn, pix0, HW, D, C, depth, feat, wg_absmax);
 }
 
 

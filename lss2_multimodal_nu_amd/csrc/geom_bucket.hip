@@ -7,6 +7,7 @@
 // tests/test_build_abi.py compiles this file to ISA and checks that the two geometry -> voxel-id kernels hold
 // no v_fma / v_fmac / v_mac / v_mad.
 #include "depthnet_body.h"
+#include "region_plan.h"
 
 namespace {
 
@@ -29,7 +30,7 @@ __device__ __forceinline__ float row_dot(const float* m, float p0, float p1, flo
 __device__ __forceinline__ int quantise_point(float g0, float g1, float g2,
                                               const float* __restrict__ dx,
                                               const float* __restrict__ bx, int b, int X, int Y,
-                                              int Z) {
+                                              int Z, int* region_xy = nullptr, int nRy = 0) {
   const float d0 = dx[0], d1 = dx[1], d2 = dx[2];
   const float lo0 = __fsub_rn(bx[0], __fmul_rn(d0, 0.5f));
   const float lo1 = __fsub_rn(bx[1], __fmul_rn(d1, 0.5f));
@@ -41,6 +42,7 @@ __device__ __forceinline__ int quantise_point(float g0, float g1, float g2,
                     (u2 > -1.0f) & (u2 < (float)Z);
   if (!kept) return -1;
   const int ix = (int)u0, iy = (int)u1, iz = (int)u2;  // v_cvt_i32_f32 truncates
+  if (region_xy) *region_xy = (ix >> 3) * nRy + (iy >> 3);  // RS = 8 cells per region side
   return ((b * X + ix) * Y + iy) * Z + iz;
 }
 
@@ -64,15 +66,40 @@ struct CalInline {
   __device__ __forceinline__ float tran(int bn, int i) const { return v[n * 21 + bn * 3 + i]; }
 };
 
-// one thread per frustum point of camera image bn; tile_x = 256-point block within the image
+// ---- region bucketing (the fused inference path) -------------------------------------------------------------
+// The BEV plane of a sample is cut into REGIONS of RS x RS cells (all z of a cell belong to it).  Points are
+// bucketed by region, not by voxel: a K3 workgroup first counts its 256 points per region in LDS (they all
+// belong to ONE sample, so rps = ceil(X/RS)*ceil(Y/RS) counters) and then issues ONE global atomic per non-empty
+// region - ~50 per workgroup instead of one per point.  The region splat kernel (splat.hip) then sums a region's
+// points into an LDS tile.  Workspace words (all zero between calls, like vox_count in the voxel path):
+//   region_count[B*rps]   points per region            (K3 counts, the splat kernel clears)
+//   region_cursor[B*rps]  slots handed out by the fill (the splat kernel clears)
+//   sample_total[B]       points kept per sample       (the splat kernel clears)
+constexpr int RS = 8, RS_SHIFT = 3;
+struct RegionArgs {
+  int32_t* region_count;
+  int32_t* region_cursor;
+  int32_t* sample_total;
+  int32_t* region_start;  // [B*rps] exclusive scan over (sample, region), written by the fill kernel
+  float* wg_absmax;       // [n2] max |feature| per K2 workgroup (plain stores)
+  int nRy, rps;
+};
+
+// one thread per frustum point of camera image bn; tile_x = 256-point block within the image.
+// hist != nullptr: LDS histogram of rps counters (region bucketing); every thread of the block must call.
 template <class Cal>
 __device__ __forceinline__ void points_to_voxels_body(
     const float* __restrict__ frustum, const Cal& cal, const float* __restrict__ dx,
     const float* __restrict__ bx, int Ncam, int DHW, int X, int Y, int Z,
     int32_t* __restrict__ voxel, int32_t* __restrict__ vox_count, float* __restrict__ geom, int tile_x,
-    int bn) {
+    int bn, int* hist = nullptr, const RegionArgs* rg = nullptr) {
   const int f = tile_x * 256 + threadIdx.x;
-  if (f >= DHW) return;
+  if (hist != nullptr) {
+    for (int i = threadIdx.x; i < rg->rps; i += 256) hist[i] = 0;
+    __syncthreads();
+  }
+  int v = -2, region = 0;  // -2: no point for this thread
+  if (f < DHW) {
   Mat3 ipr, cmb;  // block-uniform -> scalar loads
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
@@ -102,9 +129,27 @@ __device__ __forceinline__ void points_to_voxels_body(
     float* gp = geom + ((size_t)bn * DHW + f) * 3;
     gp[0] = g0; gp[1] = g1; gp[2] = g2;
   }
-  const int v = quantise_point(g0, g1, g2, dx, bx, bn / Ncam, X, Y, Z);
+  v = quantise_point(g0, g1, g2, dx, bx, bn / Ncam, X, Y, Z, &region, rg ? rg->nRy : 0);
   if (v >= 0 && vox_count) atomicAdd(vox_count + v, 1);
   voxel[(size_t)bn * DHW + f] = v;
+  }
+  if (hist != nullptr) {
+    const int b = bn / Ncam;
+    if (v >= 0) atomicAdd(&hist[region], 1);  // ds_add_u32
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < rg->rps; i += 256) {
+      const int c = hist[i];
+      if (c > 0) {
+        atomicAdd(rg->region_count + b * rg->rps + i, c);
+        mine += c;
+      }
+    }
+    // kept points of this workgroup -> the sample's total (one atomic per wave)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0 && mine > 0) atomicAdd(rg->sample_total + b, mine);
+  }
 }
 
 // grid = (ceil(D*fH*fW / 256), B*N)
@@ -130,6 +175,10 @@ struct FusedK2K3Args {
   const float* frustum; const float* inv_post_rots; const float* post_trans; const float* combine;
   const float* trans; const float* dx; const float* bx; int Ncam, DHW, X, Y, Z;
   int32_t* voxel; int32_t* vox_count; int gx3;
+  // region bucketing (use_regions != 0): K3 blocks count per region in LDS instead of per voxel in global
+  // memory, K2 blocks leave their max |feature|
+  int use_regions;
+  RegionArgs rg;
 };
 
 template <int NT>
@@ -138,12 +187,12 @@ __global__ __launch_bounds__(256) void depthnet_and_voxels_kernel(FusedK2K3Args 
   const int id = blockIdx.x;
   if (id < a.n2) {
     lss_depthnet::depthnet_softmax_f32_body<NT>(a.x, a.w, a.bias, a.Cin, a.HW, a.D, a.C, a.depth, a.feat, id % a.gx2,
-                                                id / a.gx2, lds);
+                                                id / a.gx2, lds, a.use_regions ? a.rg.wg_absmax + id : nullptr);
   } else {
     const int k = id - a.n2;
     const CalPtr cal = {a.inv_post_rots, a.post_trans, a.combine, a.trans};
     points_to_voxels_body(a.frustum, cal, a.dx, a.bx, a.Ncam, a.DHW, a.X, a.Y, a.Z, a.voxel, a.vox_count, nullptr,
-                          k % a.gx3, k / a.gx3);
+                          k % a.gx3, k / a.gx3, a.use_regions ? reinterpret_cast<int*>(lds) : nullptr, &a.rg);
   }
 }
 
@@ -154,11 +203,11 @@ __global__ __launch_bounds__(256) void depthnet_and_voxels_hostcal_kernel(FusedK
   const int id = blockIdx.x;
   if (id < a.n2) {
     lss_depthnet::depthnet_softmax_f32_body<NT>(a.x, a.w, a.bias, a.Cin, a.HW, a.D, a.C, a.depth, a.feat, id % a.gx2,
-                                                id / a.gx2, lds);
+                                                id / a.gx2, lds, a.use_regions ? a.rg.wg_absmax + id : nullptr);
   } else {
     const int k = id - a.n2;
     points_to_voxels_body(a.frustum, cal, a.dx, a.bx, a.Ncam, a.DHW, a.X, a.Y, a.Z, a.voxel, a.vox_count, nullptr,
-                          k % a.gx3, k / a.gx3);
+                          k % a.gx3, k / a.gx3, a.use_regions ? reinterpret_cast<int*>(lds) : nullptr, &a.rg);
   }
 }
 
@@ -237,6 +286,74 @@ __global__ __launch_bounds__(256) void bucket_fill_kernel(const int32_t* __restr
   const int bd = p / HW, pix = p - bd * HW;
   const int bn = bd / D, d = bd - bn * D;
   entries[vox_list[2 * v] + slot] = make_int2(((bn * HW + pix) << 7) | d, __builtin_bit_cast(int, w));
+}
+
+// Region fill (second launch of the fused inference path).  grid = (ceil(DHW/256), B*N), one thread per point:
+//   1. the workgroup scans the rps region counts of ITS sample in LDS (exclusive) and adds the totals of the
+//      samples before it: region_start; workgroup (0, first camera) of each sample also writes it out for the splat;
+//   2. every kept point takes a rank inside its (workgroup, region) group with an LDS atomic;
+//   3. one GLOBAL atomic per non-empty (workgroup, region) reserves the group's slots in the region's bucket;
+//   4. the entry {(feature row << 8) | cell in region, depth weight} goes to start + base + rank.
+// Entries of a region end up contiguous, in arbitrary order - the splat's fixed-point sums do not depend on it.
+__global__ __launch_bounds__(256) void region_fill_kernel(const int32_t* __restrict__ voxel,
+                                                          const float* __restrict__ depth, int Ncam, int D,
+                                                          int HW, int X, int Y, int Z, RegionArgs rg,
+                                                          int2* __restrict__ entries) {
+  extern __shared__ __attribute__((aligned(16))) int fl[];  // [rps] start | [rps] count -> base
+  int* rstart = fl;
+  int* rcnt = fl + rg.rps;
+  __shared__ int wave_tot[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bn = blockIdx.y, b = bn / Ncam, DHW = D * HW;
+  const int f = blockIdx.x * 256 + tid;
+  // -- 1. exclusive scan of this sample's region counts (each thread owns a contiguous run of regions)
+  const int per = (rg.rps + 255) / 256;
+  const int i0 = tid * per;
+  int run = 0;
+  for (int i = i0; i < min(i0 + per, rg.rps); ++i) run += rg.region_count[b * rg.rps + i];
+  int incl = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  int base = 0;
+  for (int bb = 0; bb < b; ++bb) base += rg.sample_total[bb];
+  __syncthreads();
+  for (int w = 0; w < wave; ++w) base += wave_tot[w];
+  int acc = base + incl - run;
+  const bool writer = blockIdx.x == 0 && bn == b * Ncam;
+  for (int i = i0; i < min(i0 + per, rg.rps); ++i) {
+    rstart[i] = acc;
+    if (writer) rg.region_start[b * rg.rps + i] = acc;
+    acc += rg.region_count[b * rg.rps + i];
+  }
+  for (int i = tid; i < rg.rps; i += 256) rcnt[i] = 0;
+  __syncthreads();
+  // -- 2. rank inside the (workgroup, region) group
+  int v = -1, region = 0, cell = 0, rank = 0;
+  if (f < DHW) v = voxel[(size_t)bn * DHW + f];
+  if (v >= 0) {
+    const int iz = v % Z, cxy = v / Z - b * X * Y;  // v = ((b*X + ix)*Y + iy)*Z + iz
+    const int ix = cxy / Y, iy = cxy - ix * Y;
+    region = (ix >> RS_SHIFT) * rg.nRy + (iy >> RS_SHIFT);
+    cell = (((ix & (RS - 1)) << RS_SHIFT) | (iy & (RS - 1))) * Z + iz;
+    rank = atomicAdd(&rcnt[region], 1);  // ds_add_rtn_u32
+  }
+  __syncthreads();
+  // -- 3. reserve the groups' slots: count -> base offset inside the region's bucket
+  for (int i = tid; i < rg.rps; i += 256) {
+    const int c = rcnt[i];
+    if (c > 0) rcnt[i] = atomicAdd(rg.region_cursor + b * rg.rps + i, c);
+  }
+  __syncthreads();
+  // -- 4. the entry
+  if (v >= 0) {
+    const int d = f / HW, pix = f - d * HW;
+    const float w = depth[(size_t)bn * DHW + f];  // depth is (BN, D, HW): flat index == point id
+    entries[rstart[region] + rcnt[region] + rank] = make_int2(((bn * HW + pix) << 8) | cell, __builtin_bit_cast(int, w));
+  }
 }
 
 // API-compat segmented sum (QuickCumsum.forward): one wave per run, lane = channel.
@@ -345,7 +462,8 @@ static int depthnet_voxels_impl(const float* frustum, const float* inv_post_rots
                                 const float* combine, const float* trans, const float* calib_host, const float* dx,
                                 const float* bx, const float* x, const float* w, const float* bias, int B, int N,
                                 int D, int fH, int fW, int Cin, int C, int X, int Y, int Z, int32_t* voxel,
-                                int32_t* vox_count, float* depth, float* feat, void* stream) {
+                                int32_t* vox_count, float* depth, float* feat, void* stream,
+                                const LssRegionPlan* plan = nullptr) {
   LSS_CHECK_PTR(frustum);
   if (calib_host == nullptr) {
     LSS_CHECK_PTR(inv_post_rots); LSS_CHECK_PTR(post_trans); LSS_CHECK_PTR(combine); LSS_CHECK_PTR(trans);
@@ -368,11 +486,22 @@ static int depthnet_voxels_impl(const float* frustum, const float* inv_post_rots
   a.frustum = frustum; a.inv_post_rots = inv_post_rots; a.post_trans = post_trans; a.combine = combine;
   a.trans = trans; a.dx = dx; a.bx = bx; a.Ncam = N; a.DHW = (int)DHW; a.X = X; a.Y = Y; a.Z = Z;
   a.voxel = voxel; a.vox_count = vox_count;
+  a.use_regions = plan != nullptr;
+  if (plan != nullptr) {
+    if (plan->n2 != a.n2 || plan->rps != plan->nRx * plan->nRy) return LSS_E_WORKSPACE;
+    a.rg.region_count = plan->region_count; a.rg.region_cursor = plan->region_cursor;
+    a.rg.sample_total = plan->sample_total; a.rg.region_start = plan->region_start;
+    a.rg.wg_absmax = plan->wg_absmax; a.rg.nRy = plan->nRy; a.rg.rps = plan->rps;
+  } else {
+    a.rg = RegionArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+  }
   a.gx3 = lss_cdiv(DHW, 256);
   const long long nblk = (long long)a.n2 + (long long)a.gx3 * B * N;
   if (nblk >= (1LL << 31)) return LSS_E_SHAPE;
   const int NT = (D + C + 15) / 16;
-  const size_t lds_bytes = (size_t)5 * NT * 16 * lss_depthnet::LDS_LD * sizeof(float);
+  size_t lds_bytes = (size_t)5 * NT * 16 * lss_depthnet::LDS_LD * sizeof(float);
+  if (plan != nullptr && (size_t)plan->rps * sizeof(int) > lds_bytes) lds_bytes = (size_t)plan->rps * sizeof(int);
+  if (lds_bytes > 64 * 1024) return LSS_E_SHAPE;
   hipStream_t st = lss_stream(stream);
   CalInline cal;
   if (calib_host != nullptr) {
@@ -415,4 +544,34 @@ extern "C" int lss_depthnet_voxels_hostcal_fwd(const float* frustum, const float
   LSS_CHECK_PTR(calib_host);
   return depthnet_voxels_impl(frustum, nullptr, nullptr, nullptr, nullptr, calib_host, dx, bx, x, w, bias, B, N, D, fH,
                               fW, Cin, C, X, Y, Z, voxel, vox_count, depth, feat, stream);
+}
+
+int lss_region_k2_blocks(int B, int N, int fH, int fW) { return lss_cdiv(fH * fW, lss_depthnet::PIX) * B * N; }
+
+int lss_region_depthnet_voxels(const float* frustum, const float* inv_post_rots, const float* post_trans,
+                               const float* combine, const float* trans, const float* calib_host, const float* dx,
+                               const float* bx, const float* x, const float* w, const float* bias, int B, int N, int D,
+                               int fH, int fW, int Cin, int C, int X, int Y, int Z, int32_t* voxel, float* depth,
+                               float* feat, const LssRegionPlan& plan, void* stream) {
+  // vox_count = nullptr: no per-voxel histogram, no per-point global atomics on this path
+  return depthnet_voxels_impl(frustum, inv_post_rots, post_trans, combine, trans, calib_host, dx, bx, x, w, bias, B, N,
+                              D, fH, fW, Cin, C, X, Y, Z, voxel, nullptr, depth, feat, stream, &plan);
+}
+
+int lss_region_fill(const int32_t* voxel, const float* depth, int B, int N, int D, int HW, int X, int Y, int Z,
+                    const LssRegionPlan& plan, int32_t* entries, void* stream) {
+  LSS_CHECK_PTR(voxel); LSS_CHECK_PTR(depth); LSS_CHECK_PTR(entries);
+  const long long DHW = (long long)D * HW;
+  // key packing: cell-in-region in 8 bits (RS*RS*Z <= 256), feature row in the 23 bits above
+  if (LSS_REGION_SIDE * LSS_REGION_SIDE * Z > 256 || (long long)B * N * HW >= (1LL << 23) || B * N > 65535)
+    return LSS_E_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(entries) & 7) != 0) return LSS_E_ALIGN;
+  RegionArgs rg{plan.region_count, plan.region_cursor, plan.sample_total, plan.region_start, plan.wg_absmax, plan.nRy,
+                plan.rps};
+  const size_t lds_bytes = (size_t)2 * plan.rps * sizeof(int);
+  if (lds_bytes > 64 * 1024) return LSS_E_SHAPE;
+  dim3 grid(lss_cdiv(DHW, 256), B * N);
+  hipLaunchKernelGGL(region_fill_kernel, grid, dim3(256), lds_bytes, lss_stream(stream), voxel, depth, N, D, HW, X, Y,
+                     Z, rg, reinterpret_cast<int2*>(entries));
+  return lss_launch_status();
 }

@@ -1,0 +1,30 @@
+// Internal (not part of the C ABI): the region-bucketed form of the fused lift-splat pipeline.
+//   launch 1  K2 || K3   depthnet + softmax  ||  frustum points -> voxel ids + per-region LDS histograms
+//   launch 2  fill       per-(workgroup, region) slot reservation, entries grouped by region
+//   launch 3  splat      one workgroup per region: LDS fixed-point segmented sums -> coalesced BEV stores
+// geom_bucket.hip implements launches 1-2, splat.hip launch 3 and the dispatch.
+#pragma once
+#include <stdint.h>
+
+struct LssRegionPlan {
+  int32_t* region_count;   // [B*rps]  zero between calls
+  int32_t* region_cursor;  // [B*rps]  zero between calls
+  int32_t* sample_total;   // [B]      zero between calls
+  int32_t* region_start;   // [B*rps]
+  float* wg_absmax;        // [n2]
+  int nRx, nRy, rps, n2;
+};
+
+constexpr int LSS_REGION_SIDE = 8;  // cells per region side
+
+// launch 1 (calib_host: HOST calibration buffer or nullptr, as lss_depthnet_voxels_hostcal_fwd)
+int lss_region_depthnet_voxels(const float* frustum, const float* inv_post_rots, const float* post_trans,
+                               const float* combine, const float* trans, const float* calib_host, const float* dx,
+                               const float* bx, const float* x, const float* w, const float* bias, int B, int N, int D,
+                               int fH, int fW, int Cin, int C, int X, int Y, int Z, int32_t* voxel, float* depth,
+                               float* feat, const LssRegionPlan& plan, void* stream);
+// launch 2
+int lss_region_fill(const int32_t* voxel, const float* depth, int B, int N, int D, int HW, int X, int Y, int Z,
+                    const LssRegionPlan& plan, int32_t* entries, void* stream);
+// K2 workgroups of launch 1 (= slots of wg_absmax)
+int lss_region_k2_blocks(int B, int N, int fH, int fW);

@@ -403,14 +403,16 @@ def test_vovnet_config4_batch8():
     dx, bx, nx = lo.gen_dx_bx(GRID["xbound"], GRID["ybound"], GRID["zbound"])
     ref, _ = vo.vovnet_lift_splat(c3, c4, dsd, csd, "v2", m8.frustum.cpu(), *calib, dx, bx, nx, B)
     mx, l2 = rel(grid8, ref)
-    assert l2 <= 1e-2 and mx <= 2e-2, (mx, l2)
+    assert l2 <= 1e-2 and mx <= 1.2e-2, (mx, l2)  # measured 3.3e-3 / 3.8e-3 (bf16 head convs)
     for i in (0, 3, 7):
         ci = [c[i:i + 1] for c in calib]
         with torch.no_grad():
             g1 = m1.get_voxels(c3[6 * i:6 * i + 6].cuda(), c4[6 * i:6 * i + 6].cuda(), *ci)
             s1, _, _ = m1({"c3": c3[6 * i:6 * i + 6].cuda(), "c4": c4[6 * i:6 * i + 6].cuda()}, *ci)
-        assert rel(g1[0], grid8[i])[1] <= 1e-5      # fp32 splat: the same sums, sample by sample
-        assert rel(s1[0], seg8[i])[1] <= 5e-3       # bf16 encoder: tile shapes are chosen from the grid size
+        # the bf16 depth-head convs pick tile shape / split-K from the grid size, so batch 1 and batch 8 round a few
+        # logits to different bf16 neighbours (measured 4e-5 on the grid, r02); the splat itself is sample-local
+        assert rel(g1[0], grid8[i])[1] <= 2e-4
+        assert rel(s1[0], seg8[i])[1] <= 5e-3
     for i in (0, 7):
         seg_ref, _ = vo.bev_encoder_transformer(ref[i:i + 1], esd)
         assert rel(seg8[i:i + 1], seg_ref)[1] <= 2e-2
