@@ -430,7 +430,18 @@ typedef struct lss_conv_launch {
 /* Enqueue `n` conv launches in order on `stream`; returns the first non-zero code. */
 int lss_conv2d_sequence(const lss_conv_launch_t* launches, int n, void* stream);
 
-/* K3 -> K2 -> K4 -> K5 in one call (same arguments as the individual entries). */
+/* The whole lift-splat level in one call (same arguments as the individual entries).
+ * With math = LSS_DT_F32 (and 64*Z <= 256, B*X*Y*Z large enough to hold the region words below) it runs the
+ * REGION-BUCKETED pipeline, three launches:
+ *   1. K2 || K3: depthnet + softmax  ||  points -> voxel ids, each workgroup counting its 256 points per 8 x 8-cell
+ *      region in LDS and issuing one global atomic per non-empty region (no per-point atomics);
+ *   2. fill: per-workgroup LDS ranks + one global atomic per (workgroup, region) -> entries grouped by region;
+ *   3. region splat: one workgroup per region, int64 fixed-point sums in an LDS tile (associative, so the
+ *      result is bit-reproducible whatever order the atomics produced), coalesced BEV stores incl. zeros.
+ * It lays its words out inside the same workspace: vox_count = [region_count | region_cursor] (zero on entry, zero
+ * on return, like the voxel histogram), vox_list = [region_start | per-workgroup max|feature|], entries as below,
+ * voxel as below (exact ids; the backward needs them).  Otherwise (bf16 depthnet math, Z > 4, LSS_SPLAT_LEGACY=1)
+ * the voxel-list pipeline K3 -> K2 -> K4 -> K5 of the individual entries runs. */
 int lss_lift_splat_forward(const float* frustum, const float* inv_post_rots, const float* post_trans,
                            const float* combine, const float* trans, const float* dx, const float* bx,
                            const float* x, const float* w, const float* bias, int B, int N, int D,

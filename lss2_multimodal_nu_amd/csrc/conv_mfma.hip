@@ -769,20 +769,12 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
   const bool col_ok = grp == 0 && ox < a.Wo && co < a.Cout;
   const size_t pixb = ((size_t)b * a.Ho + oyb) * a.Wo + ox;  // pixel index of pass 0 of half 0
   const int ystep = a.Wo * ycw, rstep = a.Wo * a.Cout;       // elements per image row
-  // residual rows: issued BEFORE the accumulators are staged, so the loads fly during the LDS
-  // write / barrier / read-back instead of stalling the store loop
-  uint4 rres[HEAD ? 1 : EPH * EPJ];
+  // residual rows of ONE staged half: requested at the top of the half's iteration, before its accumulators are
+  // staged, so the loads fly during the LDS write / barrier / read-back instead of stalling the store loop.  (Per
+  // half, not for the whole tile: 16 instead of 32 live registers in the 168-register KC = 32 kernels.)
+  uint4 rres[HEAD ? 1 : EPJ];
   const unsigned short* res = reinterpret_cast<const unsigned short*>(a.residual);
   const bool res_vec = !HEAD && res != nullptr && col_ok && (a.Cout & 7) == 0 && co + 8 <= a.Cout;
-  if (!HEAD) {
-    const unsigned short* rb = res + pixb * a.Cout + co;
-#pragma unroll
-    for (int it = 0; it < EPH * EPJ; ++it) {
-      const int row = (it / EPJ) * HROWS + (it % EPJ) * RPJ;
-      rres[it] = make_uint4(0, 0, 0, 0);
-      if (res_vec && oyb + row < a.Ho) rres[it] = *reinterpret_cast<const uint4*>(rb + row * rstep);
-    }
-  }
   unsigned short* y = reinterpret_cast<unsigned short*>(second ? a.y2 : a.y);
   const size_t obase = pixb * ycw + (co - ycol0);
   const __amdgpu_buffer_rsrc_t yrsrc =
@@ -793,6 +785,15 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
 #pragma unroll
   for (int half = 0; half < EPH; ++half) {
     const bool mine = grp == 0 && (EPH == 1 || (prow0 / HROWS) == half);  // this wave's rows belong to the half
+    if (!HEAD) {
+      const unsigned short* rb = res + pixb * a.Cout + co;
+#pragma unroll
+      for (int j = 0; j < EPJ; ++j) {
+        const int row = half * HROWS + j * RPJ;
+        rres[j] = make_uint4(0, 0, 0, 0);
+        if (res_vec && oyb + row < a.Ho) rres[j] = *reinterpret_cast<const uint4*>(rb + row * rstep);
+      }
+    }
     if (mine) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
@@ -941,7 +942,7 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
         const size_t o = obase + (size_t)(row * ystep);
         if (vec_ok) {
           if (res_vec) {
-            const uint4 rv = rres[half * EPJ + j];
+            const uint4 rv = rres[j];
             const unsigned int ru[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {

@@ -74,14 +74,12 @@ struct CalInline {
 // points into an LDS tile.  Workspace words (all zero between calls, like vox_count in the voxel path):
 //   region_count[B*rps]   points per region            (K3 counts, the splat kernel clears)
 //   region_cursor[B*rps]  slots handed out by the fill (the splat kernel clears)
-//   sample_total[B]       points kept per sample       (the splat kernel clears)
 constexpr int RS = 8, RS_SHIFT = 3;
 struct RegionArgs {
   int32_t* region_count;
   int32_t* region_cursor;
-  int32_t* sample_total;
   int32_t* region_start;  // [B*rps] exclusive scan over (sample, region), written by the fill kernel
-  float* wg_absmax;       // [n2] max |feature| per K2 workgroup (plain stores)
+  float* wg_absmax;       // [n2 + 1] max |feature| per K2 workgroup (plain stores); [n2] = their maximum (fill)
   int nRy, rps;
 };
 
@@ -137,18 +135,12 @@ __device__ __forceinline__ void points_to_voxels_body(
     const int b = bn / Ncam;
     if (v >= 0) atomicAdd(&hist[region], 1);  // ds_add_u32
     __syncthreads();
-    int mine = 0;
+    // one global atomic per non-empty (workgroup, region); nothing per sample: ~700 workgroups adding to the
+    // same word serialise at ~11 ns each (measured: +10 us on this launch), the fill kernel sums the counts instead
     for (int i = threadIdx.x; i < rg->rps; i += 256) {
       const int c = hist[i];
-      if (c > 0) {
-        atomicAdd(rg->region_count + b * rg->rps + i, c);
-        mine += c;
-      }
+      if (c > 0) atomicAdd(rg->region_count + b * rg->rps + i, c);
     }
-    // kept points of this workgroup -> the sample's total (one atomic per wave)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
-    if ((threadIdx.x & 63) == 0 && mine > 0) atomicAdd(rg->sample_total + b, mine);
   }
 }
 
@@ -297,12 +289,13 @@ __global__ __launch_bounds__(256) void bucket_fill_kernel(const int32_t* __restr
 // Entries of a region end up contiguous, in arbitrary order - the splat's fixed-point sums do not depend on it.
 __global__ __launch_bounds__(256) void region_fill_kernel(const int32_t* __restrict__ voxel,
                                                           const float* __restrict__ depth, int Ncam, int D,
-                                                          int HW, int X, int Y, int Z, RegionArgs rg,
+                                                          int HW, int X, int Y, int Z, RegionArgs rg, int n2,
                                                           int2* __restrict__ entries) {
   extern __shared__ __attribute__((aligned(16))) int fl[];  // [rps] start | [rps] count -> base
   int* rstart = fl;
   int* rcnt = fl + rg.rps;
-  __shared__ int wave_tot[4];
+  __shared__ int wave_tot[4], wave_before[4];
+  __shared__ float wave_max[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bn = blockIdx.y, b = bn / Ncam, DHW = D * HW;
   const int f = blockIdx.x * 256 + tid;
@@ -318,9 +311,14 @@ __global__ __launch_bounds__(256) void region_fill_kernel(const int32_t* __restr
     if (lane >= o) incl += t;
   }
   if (lane == 63) wave_tot[wave] = incl;
-  int base = 0;
-  for (int bb = 0; bb < b; ++bb) base += rg.sample_total[bb];
+  // points of the samples before this one (their buckets come first): sum of their region counts
+  int before = 0;
+  for (int i = tid; i < b * rg.rps; i += 256) before += rg.region_count[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+  if (lane == 0) wave_before[wave] = before;
   __syncthreads();
+  int base = wave_before[0] + wave_before[1] + wave_before[2] + wave_before[3];
   for (int w = 0; w < wave; ++w) base += wave_tot[w];
   int acc = base + incl - run;
   const bool writer = blockIdx.x == 0 && bn == b * Ncam;
@@ -348,6 +346,15 @@ __global__ __launch_bounds__(256) void region_fill_kernel(const int32_t* __restr
     if (c > 0) rcnt[i] = atomicAdd(rg.region_cursor + b * rg.rps + i, c);
   }
   __syncthreads();
+  // -- the first workgroup also reduces K2's per-workgroup max |feature| to ONE word for the splat (slot n2)
+  if (blockIdx.x == 0 && bn == 0) {
+    float m = 0.f;
+    for (int i = tid; i < n2; i += 256) m = fmaxf(m, rg.wg_absmax[i]);
+    m = lss_wave_max(m);
+    if (lane == 0) wave_max[wave] = m;
+    __syncthreads();
+    if (tid == 0) rg.wg_absmax[n2] = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+  }
   // -- 4. the entry
   if (v >= 0) {
     const int d = f / HW, pix = f - d * HW;
@@ -490,10 +497,10 @@ static int depthnet_voxels_impl(const float* frustum, const float* inv_post_rots
   if (plan != nullptr) {
     if (plan->n2 != a.n2 || plan->rps != plan->nRx * plan->nRy) return LSS_E_WORKSPACE;
     a.rg.region_count = plan->region_count; a.rg.region_cursor = plan->region_cursor;
-    a.rg.sample_total = plan->sample_total; a.rg.region_start = plan->region_start;
+    a.rg.region_start = plan->region_start;
     a.rg.wg_absmax = plan->wg_absmax; a.rg.nRy = plan->nRy; a.rg.rps = plan->rps;
   } else {
-    a.rg = RegionArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    a.rg = RegionArgs{nullptr, nullptr, nullptr, nullptr, 0, 0};
   }
   a.gx3 = lss_cdiv(DHW, 256);
   const long long nblk = (long long)a.n2 + (long long)a.gx3 * B * N;
@@ -566,12 +573,11 @@ int lss_region_fill(const int32_t* voxel, const float* depth, int B, int N, int 
   if (LSS_REGION_SIDE * LSS_REGION_SIDE * Z > 256 || (long long)B * N * HW >= (1LL << 23) || B * N > 65535)
     return LSS_E_SHAPE;
   if ((reinterpret_cast<uintptr_t>(entries) & 7) != 0) return LSS_E_ALIGN;
-  RegionArgs rg{plan.region_count, plan.region_cursor, plan.sample_total, plan.region_start, plan.wg_absmax, plan.nRy,
-                plan.rps};
+  RegionArgs rg{plan.region_count, plan.region_cursor, plan.region_start, plan.wg_absmax, plan.nRy, plan.rps};
   const size_t lds_bytes = (size_t)2 * plan.rps * sizeof(int);
   if (lds_bytes > 64 * 1024) return LSS_E_SHAPE;
   dim3 grid(lss_cdiv(DHW, 256), B * N);
   hipLaunchKernelGGL(region_fill_kernel, grid, dim3(256), lds_bytes, lss_stream(stream), voxel, depth, N, D, HW, X, Y,
-                     Z, rg, reinterpret_cast<int2*>(entries));
+                     Z, rg, plan.n2, reinterpret_cast<int2*>(entries));
   return lss_launch_status();
 }

@@ -9,9 +9,8 @@
 struct LssRegionPlan {
   int32_t* region_count;   // [B*rps]  zero between calls
   int32_t* region_cursor;  // [B*rps]  zero between calls
-  int32_t* sample_total;   // [B]      zero between calls
   int32_t* region_start;   // [B*rps]
-  float* wg_absmax;        // [n2]
+  float* wg_absmax;        // [n2 + 1]: per K2 workgroup, and their maximum (written by the fill kernel)
   int nRx, nRy, rps, n2;
 };
 

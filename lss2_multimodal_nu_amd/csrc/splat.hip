@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "lss_common.h"
+#include "region_plan.h"
 
 namespace {
 
@@ -246,6 +247,214 @@ __global__ __launch_bounds__(512) void lift_splat_fwd_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Region splat (launch 3 of the fused inference path; bucketing: geom_bucket.hip).
+// One 256-thread workgroup per REGION of 8 x 8 BEV cells (all z) of one sample.  Its points arrive as one
+// contiguous run of {(feature row << 8) | cell, depth weight} entries in ARBITRARY order; each wave takes 64 of
+// them at a time (one coalesced 512-B load), broadcasts (row, cell, weight) lane by lane through SGPRs and -
+// lane = channel - adds  w * feat[row][c]  into the region's LDS tile with an LDS atomic.  The sums are FIXED
+// POINT (int64, scale 2^(40 - e) with max|feat| < 2^e taken from K2): integer addition is associative, so the
+// result does not depend on the order the bucketing produced - run-to-run bit-reproducible without sorting
+// anything - and carries 40 bits below the largest feature (fp32 itself has 24).
+// The inner loop is instruction-issue bound (one wave-iteration per point), so it is kept to 12 instructions:
+// 3 v_readlane, 1 buffer_load (SGPR row offset), v_mul, 2 for the non-finite watch, cvt + fma + sub for the
+// fixed-point conversion (magic-number rounding: bits(x*scale + 1.5*2^52) - bits(1.5*2^52)), 1 address add,
+// ds_add_u64.  Non-finite products are only WATCHED there (running max of the magnitude bits); if one shows up the
+// region is redone by the careful loop, which flags the (cell, channel) elements it touches - those are written
+// as NaN.
+// The tile is then converted once and leaves in coalesced stores (8 x Z cells of an ix row are contiguous in
+// the NHWC layouts), zeros for empty cells included: every BEV byte is written exactly once, no memset, no
+// global atomics.  Empty regions skip LDS altogether.  The workgroup also returns its workspace counters to
+// zero for the next call.
+constexpr double FX_MAGIC = 6755399441055744.0;  // 1.5 * 2^52: bit pattern 0x4338000000000000
+constexpr int FX_MAGIC_HI = 0x43380000;
+
+template <int CPL>
+__device__ __forceinline__ void region_accumulate_careful(const float* __restrict__ feat,
+                                                          const int2* __restrict__ entries, int start, int n,
+                                                          double scale, unsigned long long* tile,
+                                                          unsigned int* flags, int wave, int lane) {
+  constexpr int C = 64 * CPL;
+  for (int c0 = wave * 64; c0 < n; c0 += 256) {
+    int key = 0;
+    float w = 0.f;
+    if (c0 + lane < n) {
+      const int2 en = entries[start + c0 + lane];
+      key = en.x;
+      w = __builtin_bit_cast(float, en.y);
+    }
+    const int cnt = min(64, n - c0);
+    for (int i = 0; i < cnt; ++i) {
+      const int k = __builtin_amdgcn_readlane(key, i);
+      const float ww = rl_f(w, i);
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        const float x = ww * feat[(size_t)(k >> 8) * C + q * 64 + lane];
+        const int o = (k & 255) * C + q * 64 + lane;
+        if (!(fabsf(x) <= 3.0e38f)) {
+          atomicOr(&flags[o >> 5], 1u << (o & 31));
+        } else {
+          const double t = __builtin_fma((double)x, scale, FX_MAGIC);
+          atomicAdd(&tile[o], (unsigned long long)(__builtin_bit_cast(long long, t) - ((long long)FX_MAGIC_HI << 32)));
+        }
+      }
+    }
+  }
+}
+
+// (An fp32 tile updated with ds_add_f32 - 7 instructions per point instead of 12 - was built and measured: 92.8 us
+// against 20.1 us for this kernel on the bench workload.  LDS float atomics are an order of magnitude slower than
+// the 64-bit integer ones on gfx950, so the fixed-point form is the fast one as well as the reproducible one.)
+template <int CPL, int LAYOUT>
+__global__ __launch_bounds__(256) void region_splat_kernel(const float* __restrict__ feat,
+                                                           const int2* __restrict__ entries, LssRegionPlan rp,
+                                                           int X, int Y, int Z, void* __restrict__ bev_) {
+  constexpr int C = 64 * CPL;
+  constexpr int RSIDE = LSS_REGION_SIDE;
+  extern __shared__ __attribute__((aligned(16))) unsigned long long tile[];  // [64*Z][C] sums, then flag words
+  __shared__ unsigned int wg_watch;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = blockIdx.x, b = r / rp.rps, rr = r - b * rp.rps;
+  const int rx = rr / rp.nRy, ry = rr - rx * rp.nRy;
+  const int ncell = RSIDE * RSIDE * Z;
+  unsigned int* flags = reinterpret_cast<unsigned int*>(tile + (size_t)ncell * C);  // [ncell*C/32]
+  const int n = rp.region_count[r];
+  const int start = rp.region_start[r];
+  const float m = rp.wg_absmax[rp.n2];  // max |feature| over K2's workgroups (reduced by the fill kernel)  // max |feature| over K2's workgroups (reduced by the fill kernel)
+  if (tid == 0) wg_watch = 0;
+  __syncthreads();  // every thread has read region_count[r]
+  if (tid == 0) {   // the counters go back to zero (workspace contract)
+    rp.region_count[r] = 0;
+    rp.region_cursor[r] = 0;
+  }
+  int e = 0;
+  if (m > 0.f && m < INFINITY) (void)frexpf(m, &e);  // m < 2^e
+  const double scale = ldexp(1.0, 40 - e);
+  const float inv_lo = ldexpf(1.0f, e - 40), inv_hi = ldexpf(1.0f, e - 8);  // 2^-(40-e), and x 2^32
+  const int zero_n = ncell * C / 2 + ncell * C / 128;  // 16-B stores that clear the sums and the flag words
+
+  if (n > 0) {
+    // The region's entries are dealt to the 4 waves in slices of `chunk` <= 64 (a multiple of 8, about n / 4): all four
+    // waves work on any region of >= 32 points.  The first slice is requested BEFORE the tile is cleared, so the
+    // round trip of that load overlaps the LDS stores and the barrier.
+    const int chunk = min(64, max(8, ((n + 3) / 4 + 7) & ~7));
+    int key = 0;
+    float w = 0.f;  // lanes past the end of a slice: weight 0 on row 0 / cell 0 - adds nothing
+    int c0 = wave * chunk;
+    if (lane < chunk && c0 + lane < n) {
+      const int2 en = entries[start + c0 + lane];
+      key = en.x;
+      w = __builtin_bit_cast(float, en.y);
+    }
+    for (int i = tid; i < zero_n; i += 256) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t frs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feat), 0, 0x7fffffff, 0x00020000);
+    unsigned long long* const my_col = tile + lane;  // lane = channel
+    unsigned int watch = 0;  // running max of |x| bit patterns: >= 0x7f800000 <=> a non-finite product went by
+    while (c0 < n) {
+      const int rowoff = (key >> 8) * (C * 4);             // byte offset of the feature row
+      const int celloff = (key & 255) * C;                 // element offset of the cell's tile row
+      const int cnt = min(chunk, n - c0);
+      for (int i0 = 0; i0 < cnt; i0 += 8) {  // i0 + 7 <= 63
+        float f[8][CPL];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int ro = __builtin_amdgcn_readlane(rowoff, i0 + u);
+#pragma unroll
+          for (int q = 0; q < CPL; ++q)
+            f[u][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frs, lane * 4 + q * 256, ro, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int co = __builtin_amdgcn_readlane(celloff, i0 + u);
+          const float ww = rl_f(w, i0 + u);
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) {
+            const float x = ww * f[u][q];
+            watch = max(watch, __builtin_bit_cast(unsigned int, x) & 0x7fffffffu);
+            const double t = __builtin_fma((double)x, scale, FX_MAGIC);
+            unsigned long long qv = __builtin_bit_cast(unsigned long long, t);
+            qv -= (unsigned long long)FX_MAGIC_HI << 32;  // one 32-bit subtract: the magic's low word is zero
+            __hip_atomic_fetch_add(my_col + co + q * 64, qv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_u64
+          }
+        }
+      }
+      c0 += 4 * chunk;
+      key = 0;
+      w = 0.f;
+      if (c0 < n && lane < chunk && c0 + lane < n) {
+        const int2 en = entries[start + c0 + lane];
+        key = en.x;
+        w = __builtin_bit_cast(float, en.y);
+      }
+    }
+    if (watch >= 0x7f800000u) atomicOr(&wg_watch, 1u);
+    __syncthreads();
+    if (wg_watch != 0) {  // rare: a non-finite product - redo the region element by element, with flags
+      __syncthreads();
+      for (int i = tid; i < zero_n; i += 256) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
+      __syncthreads();
+      region_accumulate_careful<CPL>(feat, entries, start, n, scale, tile, flags, wave, lane);
+      __syncthreads();
+    }
+  }
+
+  auto value = [&](int o) -> float {  // (cell, channel) element o of the tile as fp32
+    // int64 -> fp32 on the fp32 pipe: hi * 2^32 * 2^-s + lo * 2^-s (hi, lo the two words; |sum| < 2^56 keeps
+    // the conversion of hi exact, so the result is within one rounding of the exact quotient)
+    const unsigned long long sv = tile[o];
+    const float v = __builtin_fmaf((float)(int)(sv >> 32), inv_hi, (float)(unsigned int)sv * inv_lo);
+    return ((flags[o >> 5] >> (o & 31)) & 1u) ? __builtin_nanf("") : v;
+  };
+  const int ix0 = rx * RSIDE, iy0 = ry * RSIDE;
+  if (LAYOUT == LSS_BEV_NCHW_F32) {
+    // bev[((b*Z + iz)*C + c)][ix][iy]: a piece = the 8 iy-consecutive cells of (c, lx, iz)
+    float* bev = reinterpret_cast<float*>(bev_);
+    const bool vec_ok = (Y & 3) == 0 && iy0 + RSIDE <= Y;
+    for (int pc = tid; pc < C * RSIDE * Z; pc += 256) {
+      const int c = pc % C, t = pc / C, lx = t % RSIDE, iz = t / RSIDE;
+      const int ix = ix0 + lx;
+      if (ix >= X) continue;
+      float v[RSIDE];
+#pragma unroll
+      for (int ly = 0; ly < RSIDE; ++ly) v[ly] = n > 0 ? value(((lx * RSIDE + ly) * Z + iz) * C + c) : 0.f;
+      float* op = bev + (((size_t)b * Z + iz) * C + c) * X * Y + (size_t)ix * Y + iy0;
+      if (vec_ok) {
+        *reinterpret_cast<f32x4*>(op) = (f32x4){v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+      } else {
+#pragma unroll
+        for (int ly = 0; ly < RSIDE; ++ly)
+          if (iy0 + ly < Y) op[ly] = v[ly];
+      }
+    }
+  } else {
+    // NHWC: row of cell (ix, iy, iz) = (((b*X + ix)*Y + iy)*Z + iz) * C; a piece = 8 channels of one cell
+    for (int pc = tid; pc < ncell * (C / 8); pc += 256) {
+      const int cell = pc / (C / 8), c8 = pc % (C / 8);
+      const int iz = cell % Z, t = cell / Z, ly = t % RSIDE, lx = t / RSIDE;
+      const int ix = ix0 + lx, iy = iy0 + ly;
+      if (ix >= X || iy >= Y) continue;
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = n > 0 ? value(cell * C + c8 * 8 + k) : 0.f;
+      const size_t o = ((((size_t)b * X + ix) * Y + iy) * Z + iz) * C + c8 * 8;
+      if (LAYOUT == LSS_BEV_NHWC_F32) {
+        float* bev = reinterpret_cast<float*>(bev_);
+        *reinterpret_cast<f32x4*>(bev + o) = (f32x4){v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(bev + o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+      } else {
+        uint4 ov;
+        ov.x = lss_pack_bf2(v[0], v[1]); ov.y = lss_pack_bf2(v[2], v[3]);
+        ov.z = lss_pack_bf2(v[4], v[5]); ov.w = lss_pack_bf2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(bev_) + o) = ov;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Backward.  One wave per camera pixel (bn, pix), lane = channel; a workgroup
 // covers 16 consecutive pixels of one image so the (D+C) x 16 block of g_logits
@@ -397,6 +606,50 @@ extern "C" int lss_lift_splat_bwd(const void* grad_bev, int layout, const int32_
   return lss_launch_status();
 }
 
+// Can the region-bucketed pipeline run this problem out of the ABI's workspace?  (vox_count: the zero-between-
+// calls words; vox_list: plain scratch.)  Otherwise the voxel-list pipeline below is used.
+static bool region_plan_for(int B, int N, int D, int fH, int fW, int C, int X, int Y, int Z, int32_t* vox_count,
+                            int32_t* vox_list, LssRegionPlan* rp) {
+  if (const char* e = getenv("LSS_SPLAT_LEGACY"))
+    if (atoi(e) != 0) return false;
+  const long long nvox = (long long)B * X * Y * Z, P = (long long)B * N * D * fH * fW;
+  rp->nRx = lss_cdiv(X, LSS_REGION_SIDE);
+  rp->nRy = lss_cdiv(Y, LSS_REGION_SIDE);
+  rp->rps = rp->nRx * rp->nRy;
+  rp->n2 = lss_region_k2_blocks(B, N, fH, fW);
+  const long long nreg = (long long)B * rp->rps;
+  const size_t tile_bytes = (size_t)64 * Z * C * 8 + (size_t)64 * Z * C / 8;
+  if (rp->rps > 4096 || tile_bytes > 64 * 1024 || 64 * Z > 256 || P >= (1LL << 22) || nreg >= (1LL << 24) ||
+      (long long)B * N * fH * fW >= (1LL << 23))
+    return false;
+  if (2 * nreg > nvox || nreg + rp->n2 + 1 > 2 * nvox) return false;
+  rp->region_count = vox_count;
+  rp->region_cursor = vox_count + nreg;
+  rp->region_start = vox_list;
+  rp->wg_absmax = reinterpret_cast<float*>(vox_list + nreg);
+  return true;
+}
+
+static int region_splat_launch(const float* feat, const int32_t* entries, const LssRegionPlan& rp, int B, int C, int X,
+                               int Y, int Z, void* bev, int layout, hipStream_t st) {
+  const size_t lds = (size_t)64 * Z * C * 8 + (size_t)64 * Z * C / 8;
+  dim3 grid(B * rp.rps);
+  const int2* en = reinterpret_cast<const int2*>(entries);
+#define LSS_RS(CPL, LAY) \
+  hipLaunchKernelGGL((region_splat_kernel<CPL, LAY>), grid, dim3(256), lds, st, feat, en, rp, X, Y, Z, bev)
+  if (C == 64) {
+    if (layout == LSS_BEV_NCHW_F32) LSS_RS(1, LSS_BEV_NCHW_F32);
+    else if (layout == LSS_BEV_NHWC_F32) LSS_RS(1, LSS_BEV_NHWC_F32);
+    else LSS_RS(1, LSS_BEV_NHWC_BF16);
+  } else {
+    if (layout == LSS_BEV_NCHW_F32) LSS_RS(2, LSS_BEV_NCHW_F32);
+    else if (layout == LSS_BEV_NHWC_F32) LSS_RS(2, LSS_BEV_NHWC_F32);
+    else LSS_RS(2, LSS_BEV_NHWC_BF16);
+  }
+#undef LSS_RS
+  return lss_launch_status();
+}
+
 static int lift_splat_forward_impl(const float* frustum, const float* inv_post_rots, const float* post_trans,
                                    const float* combine, const float* trans, const float* calib_host, const float* dx,
                                    const float* bx, const float* x, const float* w, const float* bias, int B, int N,
@@ -404,6 +657,20 @@ static int lift_splat_forward_impl(const float* frustum, const float* inv_post_r
                                    int32_t* vox_count, int32_t* vox_list, int32_t* entries, int32_t* cursor,
                                    float* depth, float* feat, void* bev, int layout, int math, void* stream) {
   int rc;
+  // Region-bucketed pipeline (3 launches: K2 || K3 + LDS region histograms, fill, region splat) whenever the
+  // depthnet runs in f32 and the problem fits its limits; LSS_SPLAT_LEGACY=1 forces the voxel-list pipeline.
+  LssRegionPlan rp;
+  if (math == LSS_DT_F32 && (C == 64 || C == 128) && layout >= 0 && layout <= 2 && vox_count != nullptr &&
+      vox_list != nullptr && entries != nullptr && bev != nullptr && B > 0 && N > 0 && D > 0 && fH > 0 && fW > 0 &&
+      X > 0 && Y > 0 && Z > 0 && (reinterpret_cast<uintptr_t>(bev) & 15) == 0 &&
+      region_plan_for(B, N, D, fH, fW, C, X, Y, Z, vox_count, vox_list, &rp)) {
+    rc = lss_region_depthnet_voxels(frustum, inv_post_rots, post_trans, combine, trans, calib_host, dx, bx, x, w, bias,
+                                    B, N, D, fH, fW, Cin, C, X, Y, Z, voxel, depth, feat, rp, stream);
+    if (rc) return rc;
+    rc = lss_region_fill(voxel, depth, B, N, D, fH * fW, X, Y, Z, rp, entries, stream);
+    if (rc) return rc;
+    return region_splat_launch(feat, entries, rp, B, C, X, Y, Z, bev, layout, lss_stream(stream));
+  }
   if (calib_host != nullptr) {
     if (math != LSS_DT_F32) return LSS_E_LAYOUT;
     rc = lss_depthnet_voxels_hostcal_fwd(frustum, calib_host, dx, bx, x, w, bias, B, N, D, fH, fW, Cin, C, X, Y, Z,

@@ -1,0 +1,172 @@
+"""The region-bucketed lift-splat pipeline (K2 || K3 + LDS region histograms -> fill -> region splat; DESIGN.md
+section 3) against the fp64 oracle, against the voxel-list pipeline it replaces on the fused entry points, and
+its own contracts: voxel ids bit-exact, bit-reproducible sums whatever order the bucketing produced, workspace
+words back at zero, partial / empty regions, non-finite features confined to the cells they touch."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lss_oracle as lo  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from lss2_multimodal_nu_amd import ops as _ops
+    return _ops
+
+
+def problem(B, N, D, fH, fW, C, grid, final_dim, seed, randn_calib=False):
+    dx, bx, nx = lo.gen_dx_bx(grid["xbound"], grid["ybound"], grid["zbound"])
+    fr = lo.create_frustum(final_dim, 16, grid["dbound"])
+    assert tuple(fr.shape[:3]) == (D, fH, fW)
+    if randn_calib:  # reference smoke-test style rigs (src/model_vovnet_transformer.py:729-734): points everywhere
+        g = torch.Generator().manual_seed(seed)
+        rots, intr, prot = (torch.randn(B, N, 3, 3, generator=g) for _ in range(3))
+        trans, ptr = torch.randn(B, N, 3, generator=g), torch.randn(B, N, 3, generator=g)
+    else:
+        rots, trans, intr, prot, ptr = lo.synthetic_rig(B, N, final_dim=final_dim, train_aug=True, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(B * N, 128, fH, fW, generator=g)
+    w = torch.randn(D + C, 128, generator=g) * 128 ** -0.5
+    bias = torch.randn(D + C, generator=g) * 0.1
+    return dict(dx=dx, bx=bx, nx=[int(v) for v in nx], fr=fr, calib=(rots, trans, intr, prot, ptr), x=x, w=w, bias=bias,
+                dims=(B, N, D, fH, fW, C))
+
+
+def run(ops, pr, layout, legacy, monkeypatch, ws=None, hostcal=False):
+    B, N, D, fH, fW, C = pr["dims"]
+    X, Y, Z = pr["nx"]
+    if legacy:
+        monkeypatch.setenv("LSS_SPLAT_LEGACY", "1")
+    else:
+        monkeypatch.delenv("LSS_SPLAT_LEGACY", raising=False)
+    ws = ws or ops.SplatWorkspace(B * N * D * fH * fW, B * X * Y * Z, "cuda")
+    rots, trans, intr, prot, ptr = pr["calib"]
+    inv_pr, comb = lo.calib_matrices(rots, intr, prot)
+    c = lambda t: t.contiguous().cuda()
+    if hostcal:
+        host = torch.cat([inv_pr.reshape(-1), comb.reshape(-1), ptr.reshape(-1), trans.reshape(-1)]).float().contiguous()
+        bev, depth, feat = ops.lift_splat_forward_hostcal(c(pr["fr"]), host, c(pr["dx"]), c(pr["bx"]), c(pr["x"]),
+                                                          c(pr["w"]), c(pr["bias"]), ws, pr["dims"], (X, Y, Z), layout)
+    else:
+        bev, depth, feat = ops.lift_splat_forward(c(pr["fr"]), c(inv_pr), c(ptr), c(comb), c(trans), c(pr["dx"]),
+                                                  c(pr["bx"]), c(pr["x"]), c(pr["w"]), c(pr["bias"]), ws, pr["dims"],
+                                                  (X, Y, Z), layout)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("LSS_SPLAT_LEGACY", raising=False)
+    return bev, depth, feat, ws
+
+
+def oracle_bev(pr, depth, feat):
+    """fp64 direct segmented sum from the GPU's own depth / context tensors and the ORACLE's voxel ids."""
+    B, N, D, fH, fW, C = pr["dims"]
+    X, Y, Z = pr["nx"]
+    geom = lo.get_geometry_torch(pr["fr"], *pr["calib"]).numpy()
+    idx, kept = lo.voxel_indices_np(geom, pr["dx"].numpy(), pr["bx"].numpy(), np.asarray(pr["nx"]))
+    dep = depth.double().cpu().numpy().reshape(B, N, D, fH, fW)
+    ft = feat.double().cpu().numpy().reshape(B, N, fH, fW, C)
+    out = np.zeros((B, X, Y, Z, C))
+    bi = np.broadcast_to(np.arange(B).reshape(B, 1, 1, 1, 1), kept.shape)
+    lifted = dep[..., None] * ft[:, :, None]  # (B,N,D,fH,fW,C)
+    np.add.at(out, (bi[kept], idx[..., 0][kept], idx[..., 1][kept], idx[..., 2][kept]), lifted[kept])
+    # logical (B, Z*C, X, Y), channel = iz*C + c
+    return out.transpose(0, 3, 4, 1, 2).reshape(B, Z * C, X, Y), idx, kept
+
+
+CASES = [
+    # B, N, D, fH, fW, C, grid, final_dim, randn calibration
+    (2, 6, 41, 8, 22, 64, dict(xbound=[-50.0, 50.0, 0.5], ybound=[-50.0, 50.0, 0.5], zbound=[-10.0, 10.0, 20.0],
+                               dbound=[4.0, 45.0, 1.0]), (128, 352), False),
+    (1, 2, 5, 3, 4, 64, dict(xbound=[-10.0, 10.0, 2.0], ybound=[-10.0, 10.0, 2.0], zbound=[-4.0, 4.0, 4.0],
+                             dbound=[4.0, 9.0, 1.0]), (48, 64), True),          # 10 x 10 x 2: partial regions, Z = 2
+    (2, 3, 7, 4, 5, 128, dict(xbound=[-20.0, 20.0, 0.8], ybound=[-12.0, 12.0, 1.0], zbound=[-10.0, 10.0, 20.0],
+                              dbound=[2.0, 9.0, 1.0]), (64, 80), True),          # 50 x 24, C = 128
+    (1, 6, 41, 8, 22, 64, dict(xbound=[-50.0, 50.0, 2.0], ybound=[-50.0, 50.0, 2.0], zbound=[-10.0, 10.0, 20.0],
+                               dbound=[4.0, 45.0, 1.0]), (128, 352), False),     # coarse 50 x 50: ~70 points per cell
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_region_pipeline_vs_fp64_and_voxel_list_pipeline(ops, monkeypatch, case, layout):
+    B, N, D, fH, fW, C, grid, fd, rc = CASES[case]
+    pr = problem(B, N, D, fH, fW, C, grid, fd, seed=case, randn_calib=rc)
+    bev, depth, feat, ws = run(ops, pr, layout, False, monkeypatch)
+    bev_l, depth_l, feat_l, ws_l = run(ops, pr, layout, True, monkeypatch)
+    X, Y, Z = pr["nx"]
+    assert tuple(bev.shape) == (B, Z * C, X, Y)
+    # same K2 / K3 kernels in both pipelines
+    assert torch.equal(depth, depth_l) and torch.equal(feat, feat_l) and torch.equal(ws.voxel, ws_l.voxel)
+    ref, idx, kept = oracle_bev(pr, depth, feat)
+    # voxel ids: exact against the oracle
+    vid = np.where(kept, ((np.broadcast_to(np.arange(B).reshape(B, 1, 1, 1, 1), kept.shape) * X + idx[..., 0]) * Y
+                          + idx[..., 1]) * Z + idx[..., 2], -1)
+    assert np.array_equal(ws.voxel.cpu().numpy().reshape(vid.shape), vid)
+    # region pipeline: fixed-point sums, exact to one fp32 rounding; voxel-list pipeline: fp32 sums of up to ~70 terms
+    # per cell, a few 1e-7 of max|ref|; bf16 output: one more rounding of the sum
+    tol = 2e-6 if layout != 2 else 4e-3
+    for got in (bev, bev_l):
+        g = got.float().cpu().numpy().astype(np.float64)
+        assert np.abs(g - ref).max() <= tol * max(np.abs(ref).max(), 1e-30)
+        assert np.array_equal(g != 0, ref != 0) or layout == 2  # empty cells are exact zeros
+    # workspace contract: the zero-between-calls words are zero again
+    assert int(ws.vox_count.abs().sum()) == 0 and int(ws.cursor.abs().sum()) == 0
+
+
+def test_region_pipeline_is_bit_reproducible_and_workspace_reusable(ops, monkeypatch):
+    B, N, D, fH, fW, C, grid, fd, rc = CASES[0]
+    pr = problem(B, N, D, fH, fW, C, grid, fd, seed=11)
+    first, _, _, ws = run(ops, pr, 0, False, monkeypatch)
+    first = first.clone()
+    for _ in range(5):  # the atomics hand out slots in a different order every launch
+        again, _, _, _ = run(ops, pr, 0, False, monkeypatch, ws=ws)
+        assert torch.equal(again, first)
+    host, _, _, _ = run(ops, pr, 0, False, monkeypatch, ws=ws, hostcal=True)
+    assert torch.equal(host, first)
+    # interleaving with the voxel-list pipeline on the same workspace leaves both intact
+    legacy, _, _, _ = run(ops, pr, 0, True, monkeypatch, ws=ws)
+    again, _, _, _ = run(ops, pr, 0, False, monkeypatch, ws=ws)
+    assert torch.equal(again, first)
+    assert float((legacy - first).abs().max()) <= 2e-6 * float(first.abs().max())
+
+
+def test_region_pipeline_nonfinite_feature_stays_in_its_cells(ops, monkeypatch):
+    B, N, D, fH, fW, C, grid, fd, rc = CASES[0]
+    pr = problem(B, N, D, fH, fW, C, grid, fd, seed=5)
+    clean, depth, feat, ws = run(ops, pr, 1, False, monkeypatch)
+    clean = clean.clone()
+    # make ONE context channel of ONE camera pixel infinite through its bias-free weight row: x is finite, so
+    # poison the input feature column of that pixel instead
+    pr2 = dict(pr)
+    x = pr["x"].clone()
+    x[3, :, 2, 7] = float("inf")
+    pr2["x"] = x
+    bad, depth2, feat2, _ = run(ops, pr2, 1, False, monkeypatch, ws=ws)
+    nonfinite = ~torch.isfinite(bad)
+    assert bool(nonfinite.any())
+    # only cells that pixel's 41 frustum points fall into may differ from the clean run
+    geom = lo.get_geometry_torch(pr["fr"], *pr["calib"]).numpy()
+    idx, kept = lo.voxel_indices_np(geom, pr["dx"].numpy(), pr["bx"].numpy(), np.asarray(pr["nx"]))
+    b, n = 3 // N, 3 % N
+    touched = torch.zeros(B, pr["nx"][0], pr["nx"][1], dtype=torch.bool)
+    for d in range(D):
+        if kept[b, n, d, 2, 7]:
+            touched[b, idx[b, n, d, 2, 7, 0], idx[b, n, d, 2, 7, 1]] = True
+    changed = (bad != clean) & ~(torch.isnan(bad) & torch.isnan(clean))
+    assert not bool(changed.cpu().any(1)[~touched].any())
+    assert int(ws.vox_count.abs().sum()) == 0
+
+
+def test_region_pipeline_all_points_dropped(ops, monkeypatch):
+    """A rig that looks away from the grid: every region is empty, the output is all zeros, counters stay zero."""
+    B, N, D, fH, fW, C, grid, fd, rc = CASES[1]
+    pr = problem(B, N, D, fH, fW, C, grid, fd, seed=2, randn_calib=True)
+    rots, trans, intr, prot, ptr = pr["calib"]
+    pr["calib"] = (rots, trans + 1e4, intr, prot, ptr)
+    for layout in (0, 1, 2):
+        bev, _, _, ws = run(ops, pr, layout, False, monkeypatch)
+        assert float(bev.float().abs().sum()) == 0.0 and int((ws.voxel >= 0).sum()) == 0
+        assert int(ws.vox_count.abs().sum()) == 0
