@@ -353,23 +353,24 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     tgt = torch.randint(0, 4, (B, 200, 200), device=dev)
     weight = torch.tensor([1.0, 10.0, 5.0, 10.0], device=dev)         # ref: src/tools.py:234
 
-    from lss2_multimodal_nu_amd.tools import weighted_cross_entropy
-
-    def loss_fn(y):  # SimpleLoss, ref: src/tools.py:221-231 (fused HIP forward/backward)
-        return weighted_cross_entropy(y.float(), tgt, weight)
-
-    amp = args.precision == "bf16"  # bf16 autocast for the (library) BevEncode convs, fp32 master weights
+    amp = args.precision == "bf16"  # bf16 autocast: native conv + BatchNorm units; fp32 master weights
 
     class _Amp(torch.nn.Module):
+        """loss = SimpleLoss()(model(x, calib...), tgt) (ref: pre_train.py:54-58, src/tools.py:221-231) through the
+        model's fused entry: 1x1 head + log-softmax + weighted NLL in one HIP kernel per direction, no logits tensor."""
+
         def __init__(self, inner):
             super().__init__()
             self.inner = inner
 
         def forward(self, *a):
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-                return self.inner(*a)
+                return self.inner.forward_loss(*a, tgt)  # class weights [1, 10, 5, 10]: the model's default
 
     wrapped = _Amp(m)
+
+    def loss_fn(loss):
+        return loss
 
     def one():  # ref: train.py:49-66 (zero_grad, forward, loss, backward, clip 5.0, Adam) + the DP all-reduce
         dp.train_step(wrapped, bucket, opt, loss_fn, (feats,) + tuple(calib), clip=5.0)

@@ -484,6 +484,25 @@ int lss_lift_splat_forward_hostcal(const float* frustum, const float* calib_host
                                    int32_t* entries, int32_t* cursor, float* depth, float* feat,
                                    void* bev, int layout, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Fused 1x1 head + log-softmax + weighted NLL, forward and backward.
+ * replaces: `up2[4]` = nn.Conv2d(128, outC, 1) (src/modules.py:115) followed by nn.CrossEntropyLoss(weight) of
+ *           SimpleLoss / MultiLoss (src/tools.py:221-238), and their autograd: the (B, outC, H, W) logits are
+ *           neither written nor read - the loss comes straight from the last activation.
+ *   y (M, Cin) bf16 NHWC rows of the last conv + BatchNorm + ReLU unit, M = B*H*W, Cin = 128;
+ *   head_w (K, Cin) fp32, head_b (K) fp32, K = 4 or 8; target (M) int64 (entries outside [0, K) are ignored);
+ *   class_w (K) fp32.  loss = sum_p class_w[t_p] * (logsumexp(logit_p) - logit_p[t_p]) / sum_p class_w[t_p].
+ *   workspace: lss_head_ce_workspace_bytes(K) bytes.  sums (2) fp32 out: {sum w*nll, sum w}, kept for the backward.
+ *   backward: dy (M, Cin) bf16 = head_w^T . g with g = grad_loss[0] * class_w[t] * (softmax - onehot) / sums[1];
+ *             d_head_w (K, Cin) fp32 = g^T . y;  d_head_b (K) fp32 = sum_p g.  Fixed summation order throughout. */
+size_t lss_head_ce_workspace_bytes(int K);
+int lss_head_ce_fwd(const void* y, const float* head_w, const float* head_b, const long long* target,
+                    const float* class_w, long long M, int Cin, int K, float* workspace, float* sums, float* loss,
+                    void* stream);
+int lss_head_ce_bwd(const void* y, const float* head_w, const float* head_b, const long long* target,
+                    const float* class_w, long long M, int Cin, int K, const float* sums, const float* grad_loss,
+                    float* workspace, void* dy, float* d_head_w, float* d_head_b, void* stream);
+
 /* ---- data-parallel gradient step (the reference has no collective on this path: its loop is
  * `loss.backward(); clip_grad_norm_(5.0); opt.step()`, train.py:63-65, on one device) --------------------------
  * One process per GPU; the flat fp32 gradient buffer (every p.grad is a view of it) is summed in place over

@@ -29,6 +29,7 @@ from .heads import (BevPost, Embedder_f1, Embedder_f2, Embedder_lr1, Embedder_lr
                     SceneUnder)
 from .modules import BevEncode, CamEncode, _PRECISIONS, _needs_autograd, default_precision
 from .tools import QuickCumsum, cumsum_trick, gen_dx_bx  # noqa: F401  (reference's import surface)
+from .tools import head_weighted_cross_entropy
 
 
 class TrunkFeatures(nn.Module):
@@ -344,6 +345,20 @@ class _LiftSplatMixin:
         return be.forward_nhwc(grid.permute(0, 2, 3, 1), dt)
 
 
+_class_weight_cache = {}
+
+
+def _bev_class_weights(device, class_weights=None):
+    """ref src/tools.py:224,236: CrossEntropyLoss(weight=[1, 10, 5, 10]).  Cached per (device, values): no
+    host-to-device copy per training step."""
+    vals = (1.0, 10.0, 5.0, 10.0) if class_weights is None else tuple(float(v) for v in class_weights)
+    key = (str(device), vals)
+    t = _class_weight_cache.get(key)
+    if t is None:
+        t = _class_weight_cache[key] = torch.tensor(vals, dtype=torch.float32, device=device)
+    return t
+
+
 class LSS(_LiftSplatMixin, nn.Module):
     def __init__(self, bsize, grid_conf, data_aug_conf, outC, encoder=None, precision=None):
         nn.Module.__init__(self)
@@ -352,6 +367,15 @@ class LSS(_LiftSplatMixin, nn.Module):
     def forward(self, x, rots, trans, intrins, post_rots, post_trans):
         x = self.encoder(x)
         return self._bev(x, rots, trans, intrins, post_rots, post_trans)
+
+    def forward_loss(self, x, rots, trans, intrins, post_rots, post_trans, binimgs, class_weights=None):
+        """`SimpleLoss()(self(x, ...), binimgs)` - the training loop body of the reference's pre_train.py:54-58 (loss:
+        src/tools.py:221-231) - as ONE differentiable scalar with the 1x1 head and the weighted cross-entropy fused
+        (SURVEY.md 8f-3): the (B, outC, X, Y) logits are never materialised.  Not part of the reference's API: an
+        opt-in entry for training loops that only need the loss; `forward` + `SimpleLoss` give the same value."""
+        x = self.encoder(x)
+        y = self.bevencode.features(self.get_voxels(x, rots, trans, intrins, post_rots, post_trans))
+        return head_weighted_cross_entropy(y, self.bevencode.up2[4], binimgs, _bev_class_weights(y.device, class_weights))
 
 
 class BEV_TXT(_LiftSplatMixin, nn.Module):
@@ -378,9 +402,29 @@ class BEV_TXT(_LiftSplatMixin, nn.Module):
     def forward(self, x, rots, trans, intrins, post_rots, post_trans):
         x = self.encoder(x)
         bev = self._bev(x, rots, trans, intrins, post_rots, post_trans)
+        act_f, desc = self._txt_heads(x, bev.detach()[:, :, 60:140, 56:144])
+        return bev, act_f, desc
 
-        # TXT half: the BEV crop around the ego vehicle joins every camera's features
-        bev_post = self.bevpost(bev.detach()[:, :, 60:140, 56:144])
+    def forward_loss(self, x, rots, trans, intrins, post_rots, post_trans, binimgs, act_gt, desc_gt):
+        """`MultiLoss(*self(x, ...), binimgs, act_gt, desc_gt)` (ref train.py:52-62, src/tools.py:234-251) as one
+        differentiable scalar with the BEV head + weighted cross-entropy fused; the TXT heads get the logits of
+        their 80 x 88 crop only (detached, as in `forward`).  Opt-in, like `LSS.forward_loss`."""
+        x = self.encoder(x)
+        y = self.bevencode.features(self.get_voxels(x, rots, trans, intrins, post_rots, post_trans))
+        head = self.bevencode.up2[4]
+        loss_bev = head_weighted_cross_entropy(y, head, binimgs, _bev_class_weights(y.device))
+        with torch.no_grad():
+            crop = head(y[:, :, 60:140, 56:144].float())
+        act_f, desc = self._txt_heads(x, crop)
+        F = torch.nn.functional
+        w1 = torch.tensor([1.0, 5.0, 5.0, 5.0], device=y.device)
+        w2 = torch.tensor([1.0, 5.0, 5.0, 5.0, 1.0, 1.0, 1.0, 1.0], device=y.device)
+        return (loss_bev + F.binary_cross_entropy_with_logits(act_f, act_gt, weight=w1)
+                + F.binary_cross_entropy_with_logits(desc, desc_gt, weight=w2))
+
+    def _txt_heads(self, x, bev_crop):
+        """TXT half: the BEV crop around the ego vehicle joins every camera's features (ref :285-334)."""
+        bev_post = self.bevpost(bev_crop)
         scene = self.sceneunder(x)
         ncams = self.data_aug_conf["Ncams"]
         cam = lambda i: scene[i::ncams]  # noqa: E731
@@ -392,7 +436,7 @@ class BEV_TXT(_LiftSplatMixin, nn.Module):
         y_f = self.embeder_f2(torch.cat([self.embeder_f1(cam(1)), bev_post], dim=1))
         desc_f, act_f = self.predictorf1(y_f), self.predictorf2(y_f)
         desc = torch.cat([desc_f, side(0), side(3), side(2), side(5)], dim=1)
-        return bev, act_f, desc
+        return act_f, desc
 
 
 def compile_model_lss(bsize, grid_conf, data_aug_conf, outC, **kw):

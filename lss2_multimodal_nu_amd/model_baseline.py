@@ -13,10 +13,12 @@ The heads (8 x 8 x 22 values per sample) are stock PyTorch like the other TXT he
 section 2: out of the hot path); under autograd their gradient flows back into the BEV map, as in
 the reference.
 """
+import torch
 from torch import nn
 
 from .heads import BevPost, Embedder_f2, Predictor, SceneUnder
-from .model_BEV_TXT import LSS, _LiftSplatMixin, compile_model_lss  # noqa: F401
+from .model_BEV_TXT import LSS, _LiftSplatMixin, _bev_class_weights, compile_model_lss  # noqa: F401
+from .tools import head_weighted_cross_entropy
 
 
 class BEV_TXT(_LiftSplatMixin, nn.Module):
@@ -39,6 +41,21 @@ class BEV_TXT(_LiftSplatMixin, nn.Module):
         bev = self._bev(x, rots, trans, intrins, post_rots, post_trans)
         bev_post = self.embeder_bev(self.bevpost(bev[:, :, 60:140, 56:144]))
         return bev, self.predictor_bev1(bev_post), self.predictor_bev2(bev_post)
+
+
+    def forward_loss(self, x, rots, trans, intrins, post_rots, post_trans, binimgs, act_gt, desc_gt):
+        """`MultiLoss(*self(x, ...), binimgs, act_gt, desc_gt)` with the BEV head + weighted cross-entropy fused
+        (see `model_BEV_TXT.BEV_TXT.forward_loss`); the heads' crop logits stay differentiable (ref :283)."""
+        x = self.encoder(x)
+        y = self.bevencode.features(self.get_voxels(x, rots, trans, intrins, post_rots, post_trans))
+        head = self.bevencode.up2[4]
+        loss_bev = head_weighted_cross_entropy(y, head, binimgs, _bev_class_weights(y.device))
+        bev_post = self.embeder_bev(self.bevpost(head(y[:, :, 60:140, 56:144].float())))
+        F = torch.nn.functional
+        w1 = torch.tensor([1.0, 5.0, 5.0, 5.0], device=y.device)
+        w2 = torch.tensor([1.0, 5.0, 5.0, 5.0, 1.0, 1.0, 1.0, 1.0], device=y.device)
+        return (loss_bev + F.binary_cross_entropy_with_logits(self.predictor_bev1(bev_post), act_gt, weight=w1)
+                + F.binary_cross_entropy_with_logits(self.predictor_bev2(bev_post), desc_gt, weight=w2))
 
 
 def compile_model_onlybev(bsize, grid_conf, data_aug_conf, outC, **kw):

@@ -648,7 +648,10 @@ class BevEncode(nn.Module):
         self._up2a = _FoldedConv(self.up2[1], self.up2[2])
         self._up2b = _FoldedConv(self.up2[4], None)
 
-    def _forward_autograd(self, x):
+    def features(self, x):
+        """Differentiable path up to (not including) the 1x1 head `up2[4]`: (B, inC, X, Y) -> (B, 128, X, Y), the
+        activation `tools.head_weighted_cross_entropy` fuses the head and the loss on."""
+        x = x.float() if x.dtype != torch.float32 else x
         if _native_training() and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)  # the whole chain then stays NHWC
         x = _train_bn_act(self.bn1, self.conv1(x), relu=True)
@@ -656,7 +659,10 @@ class BevEncode(nn.Module):
         x = self.layer3(self.layer2(x1))
         x = self.up1(x, x1)
         u = self.up2
-        return u[4](_train_conv_bn_act(u[1], u[2], x, relu=True, up=u[0])).float()
+        return _train_conv_bn_act(u[1], u[2], x, relu=True, up=u[0])
+
+    def _forward_autograd(self, x):
+        return self.up2[4](self.features(x)).float()
 
     def invalidate_plan(self):
         """Drop the cached launch lists (called whenever parameters may have changed)."""

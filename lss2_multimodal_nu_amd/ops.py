@@ -821,6 +821,55 @@ def weighted_ce_bwd(logits, target, weight, sums, grad_loss):
     return g
 
 
+_head_ce_ws = {}
+
+
+def _head_ce_workspace(K, device):
+    key = (K, str(device))
+    ws = _head_ce_ws.get(key)
+    if ws is None:
+        nbytes = N.lib().lss_head_ce_workspace_bytes(K)
+        if nbytes == 0:
+            raise ValueError("fused head + cross-entropy supports 4 or 8 classes")
+        ws = _head_ce_ws[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    return ws
+
+
+def head_ce_fwd(y, head_w, head_b, target, class_w):
+    """Fused 1x1 head + weighted cross-entropy.  y (..., 128) contiguous bf16 NHWC rows; head_w (K, 128) fp32;
+    head_b (K); target int64 with y's leading shape; class_w (K).  Returns (loss 0-d tensor, sums (2,))."""
+    K, Cin = head_w.shape
+    if y.dtype != torch.bfloat16 or not y.is_contiguous() or y.shape[-1] != Cin:
+        raise ValueError("y must be contiguous bf16 rows of %d channels" % Cin)
+    _f32c(head_w, "head_w", (K, Cin))
+    _f32c(head_b, "head_b", (K,))
+    _f32c(class_w, "class_w", (K,))
+    M = y.numel() // Cin
+    if target.dtype != torch.int64 or not target.is_contiguous() or target.numel() != M or not target.is_cuda:
+        raise ValueError("target must be a contiguous int64 GPU tensor with one entry per pixel")
+    out = torch.empty(3, dtype=torch.float32, device=y.device)
+    with _timed("head_ce_fwd"):
+        N.check(N.lib().lss_head_ce_fwd(N.ptr(y), N.ptr(head_w), N.ptr(head_b), N.ptr(target), N.ptr(class_w), M, Cin, K,
+                                        N.ptr(_head_ce_workspace(K, y.device)), out.data_ptr(), out.data_ptr() + 8,
+                                        N.stream()), "lss_head_ce_fwd")
+    return out[2].view(()), out[:2]
+
+
+def head_ce_bwd(y, head_w, head_b, target, class_w, sums, grad_loss):
+    """Backward of head_ce_fwd: returns (dy bf16 like y, d_head_w (K, Cin) fp32, d_head_b (K) fp32)."""
+    K, Cin = head_w.shape
+    M = y.numel() // Cin
+    dy = torch.empty_like(y)
+    dw = torch.empty(K, Cin, dtype=torch.float32, device=y.device)
+    db = torch.empty(K, dtype=torch.float32, device=y.device)
+    gl = grad_loss.reshape(1).float().contiguous()
+    with _timed("head_ce_bwd"):
+        N.check(N.lib().lss_head_ce_bwd(N.ptr(y), N.ptr(head_w), N.ptr(head_b), N.ptr(target), N.ptr(class_w), M, Cin, K,
+                                        N.ptr(sums), N.ptr(gl), N.ptr(_head_ce_workspace(K, y.device)), N.ptr(dy),
+                                        N.ptr(dw), N.ptr(db), N.stream()), "lss_head_ce_bwd")
+    return dy, dw, db
+
+
 def pack_conv_weight_s2d(w_oihw, pad):
     """OIHW fp32 of a stride-2 k x k conv -> bf16 [tap'][Cout][4*Cin] for conv2d_s2_nhwc."""
     Cout, Cin, K, K2 = w_oihw.shape

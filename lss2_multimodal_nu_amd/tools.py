@@ -94,6 +94,46 @@ def weighted_cross_entropy(ypred, ytgt, weight):
     return torch.nn.functional.cross_entropy(ypred, ytgt, weight=weight)
 
 
+class _HeadCEFn(torch.autograd.Function):
+    """loss = CrossEntropy(weight)(conv1x1(y; W, b), target) with the head and the loss in ONE HIP pass each way
+    (csrc/loss.hip: lss_head_ce_fwd / _bwd).  y: logical (B, Cin, H, W) tensor whose memory is NHWC bf16 (what the
+    conv + BatchNorm + ReLU training unit hands over); W (K, Cin, 1, 1), b (K)."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias, target, class_w):
+        yn = y.permute(0, 2, 3, 1)
+        if yn.dtype != torch.bfloat16:
+            yn = yn.to(torch.bfloat16)
+        yn = yn.contiguous()
+        w2 = weight.detach().float().reshape(weight.shape[0], -1).contiguous()
+        b1 = bias.detach().float().contiguous()
+        cw = class_w.detach().float().contiguous()
+        t = target.contiguous()
+        loss, sums = ops.head_ce_fwd(yn, w2, b1, t, cw)
+        ctx.save_for_backward(yn, w2, b1, t, cw, sums)
+        ctx.meta = (y.dtype, weight.shape, weight.dtype, bias.dtype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        yn, w2, b1, t, cw, sums = ctx.saved_tensors
+        ydt, wshape, wdt, bdt = ctx.meta
+        dy, dw, db = ops.head_ce_bwd(yn, w2, b1, t, cw, sums, g)
+        dy = dy.permute(0, 3, 1, 2)
+        return (dy if dy.dtype == ydt else dy.to(ydt)), dw.view(wshape).to(wdt), db.to(bdt), None, None
+
+
+def head_weighted_cross_entropy(y, head, ytgt, weight):
+    """nn.CrossEntropyLoss(weight=weight)(head(y), ytgt) for a 1x1 `head` = nn.Conv2d(128, K, 1) applied to the
+    (B, 128, H, W) activation y: fused into one HIP kernel per direction on the GPU when the shapes
+    fit (128 input channels, 4 or 8 classes); the two separate ops otherwise."""
+    if (y.is_cuda and y.dim() == 4 and y.shape[1] == 128 and head.kernel_size == (1, 1) and head.bias is not None
+            and head.out_channels in (4, 8) and ytgt.dtype == torch.int64
+            and tuple(ytgt.shape) == (y.shape[0], y.shape[2], y.shape[3])):
+        return _HeadCEFn.apply(y, head.weight, head.bias, ytgt, weight)
+    return weighted_cross_entropy(head(y).float(), ytgt, weight)
+
+
 class SimpleLoss(torch.nn.Module):
     """ref: src/tools.py:221-231 - weighted 4-class BEV cross-entropy, class weights [1, 10, 5, 10]."""
 

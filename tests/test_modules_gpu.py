@@ -472,3 +472,79 @@ def test_histogram_guard_rezeroes_the_workspace_after_a_failed_call(model, golde
         assert int(ws.vox_count.abs().sum()) == 0 and int(ws.cursor.abs().sum()) == 0
     with torch.no_grad():
         assert torch.equal(model.get_voxels(x, *calib), good)
+
+
+@pytest.mark.parametrize("K,shape", [(4, (2, 37, 50)), (8, (1, 9, 7)), (4, (4, 200, 200))])
+def test_fused_head_cross_entropy_vs_cpu_fp64(K, shape):
+    """1x1 head + log-softmax + weighted NLL in one kernel per direction (csrc/loss.hip), against the
+    same expression evaluated on the CPU in fp64 (ref: Conv2d(128, K, 1) -> nn.CrossEntropyLoss(weight))."""
+    from lss2_multimodal_nu_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(K * H)
+    y = (torch.randn(B, H, W, 128, generator=g)).relu().bfloat16()  # what the conv + BN + ReLU unit hands over
+    hw = torch.randn(K, 128, generator=g) * 128 ** -0.5
+    hb = torch.randn(K, generator=g) * 0.1
+    t = torch.randint(0, K, (B, H, W), generator=g)
+    t[0, :2] = -100  # ignored rows
+    cw = torch.rand(K, generator=g) * 9 + 1
+    loss, sums = ops.head_ce_fwd(y.cuda(), hw.cuda(), hb.cuda(), t.cuda(), cw.cuda())
+    dy, dw, db = ops.head_ce_bwd(y.cuda(), hw.cuda(), hb.cuda(), t.cuda(), cw.cuda(), sums, torch.tensor(1.7).cuda())
+    yr = y.double().requires_grad_(True)
+    wr, br = hw.double().requires_grad_(True), hb.double().requires_grad_(True)
+    logits = torch.einsum("bhwc,kc->bkhw", yr, wr) + br.view(1, K, 1, 1)
+    ref = torch.nn.functional.cross_entropy(logits, t, weight=cw.double())
+    (ref * 1.7).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-5 * abs(float(ref))
+    np.testing.assert_allclose(dw.cpu().double().numpy(), wr.grad.numpy(), rtol=2e-4, atol=2e-5 * float(wr.grad.abs().max()))
+    np.testing.assert_allclose(db.cpu().double().numpy(), br.grad.numpy(), rtol=2e-4, atol=2e-5 * float(br.grad.abs().max()))
+    # dy is stored bf16: one rounding
+    assert float((dy.cpu().double() - yr.grad).abs().max()) <= 5e-3 * float(yr.grad.abs().max())
+    # bit-reproducible
+    loss2, _ = ops.head_ce_fwd(y.cuda(), hw.cuda(), hb.cuda(), t.cuda(), cw.cuda())
+    _, dw2, _ = ops.head_ce_bwd(y.cuda(), hw.cuda(), hb.cuda(), t.cuda(), cw.cuda(), sums, torch.tensor(1.7).cuda())
+    assert torch.equal(loss, loss2) and torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize("variant", ["lss", "txt", "onlybev"])
+def test_forward_loss_equals_forward_plus_reference_loss(variant):
+    """`forward_loss` (fused head + CE) against the reference's two-step form `Loss(model(...), targets)` on the same
+    weights: same scalar, same gradients (bf16 autocast training, native conv + BN units)."""
+    import copy
+    torch.manual_seed(21)
+    B = 2
+    make = {"lss": L.compile_model_lss, "txt": L.compile_model_bevtxt, "onlybev": L.compile_model_onlybev}[variant]
+    m = make(B, GRID, AUG, 4).cuda().train()
+    with torch.no_grad():  # zero_init_residual would hide half the net from the gradient check
+        for blk in list(m.bevencode.layer1) + list(m.bevencode.layer2) + list(m.bevencode.layer3):
+            blk.bn2.weight.fill_(0.7)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m2 = copy.deepcopy(m)
+    calib = lo.synthetic_rig(B, train_aug=True, seed=3)
+    x = torch.randn(B * 6, 512, 8, 22).cuda()
+    tgt = torch.randint(0, 4, (B, 200, 200)).cuda()
+    act_gt, desc_gt = torch.rand(B, 4).round().cuda(), torch.rand(B, 8).round().cuda()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        if variant == "lss":
+            fused = m.forward_loss(x, *calib, tgt)
+            two = L.SimpleLoss().cuda()(m2(x, *calib).float(), tgt)
+        else:
+            fused = m.forward_loss(x, *calib, tgt, act_gt, desc_gt)
+            two = L.MultiLoss(*[o.float() for o in m2(x, *calib)], tgt, act_gt, desc_gt)
+    assert abs(float(fused) - float(two)) <= 2e-3 * abs(float(two))
+    fused.backward()
+    two.backward()
+    checked = 0
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        if p1.grad is None or p2.grad is None:
+            assert p1.grad is None and p2.grad is None, n1
+            continue
+        a, b = p1.grad.float().flatten(), p2.grad.float().flatten()
+        if float(b.norm()) == 0:
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+        assert cos > 0.99, (n1, cos)
+        assert abs(float(a.norm()) / float(b.norm()) - 1) < 0.05, n1
+        checked += 1
+    assert checked > 40
