@@ -83,18 +83,26 @@ __global__ __launch_bounds__(256) void weighted_ce_kernel(const float* __restric
   }
 }
 
-// sums[0] = sum w*nll, sums[1] = sum w, loss = sums[0] / sums[1]
+// sums[0] = sum w*nll, sums[1] = sum w, loss = sums[0] / sums[1].  One wave: lane i sums partials i, i + 64, ... in
+// order, then a fixed shuffle tree (a single thread walking 1024 partials cost 59 us).
 __global__ void weighted_ce_finalize_kernel(const float* __restrict__ part, int nblk, float* __restrict__ sums,
                                             float* __restrict__ loss) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
   float a = 0.f, b = 0.f;
-  for (int k = 0; k < nblk; ++k) {
+  for (int k = threadIdx.x; k < nblk; k += 64) {
     a += part[2 * k];
     b += part[2 * k + 1];
   }
-  sums[0] = a;
-  sums[1] = b;
-  loss[0] = a / b;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  if (threadIdx.x == 0) {
+    sums[0] = a;
+    sums[1] = b;
+    loss[0] = a / b;
+  }
 }
 
 }  // namespace
@@ -143,7 +151,7 @@ namespace {
 // registers per lane, meet in LDS per workgroup and leave as per-workgroup partials that a second kernel sums in a
 // fixed order.
 constexpr int HC_MAXK = 8;
-constexpr int HC_BLOCKS = 1024;
+constexpr int HC_BLOCKS = 512;
 
 template <int DPP>
 __device__ __forceinline__ float hc_dpp(float x) {
@@ -307,15 +315,20 @@ __global__ __launch_bounds__(256) void head_ce_kernel(const unsigned short* __re
   }
 }
 
-// dW[k][c], db[k] = fixed-order sums of the per-workgroup partials
+// dW[k][c], db[k] = fixed-order sums of the per-workgroup partials: one wave per output element, lane i takes
+// partials i, i + 64, ... in order, then a fixed shuffle tree (grid = n / 4 workgroups of 4 waves)
 __global__ __launch_bounds__(256) void head_ce_reduce_kernel(const float* __restrict__ dw_part, int nblk, int n,
                                                              float* __restrict__ dw, float* __restrict__ db, int ndw) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (e >= n) return;
   float a = 0.f;
-  for (int k = 0; k < nblk; ++k) a += dw_part[(size_t)k * n + e];
-  if (e < ndw) dw[e] = a;
-  else db[e - ndw] = a;
+  for (int k = lane; k < nblk; k += 64) a += dw_part[(size_t)k * n + e];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (lane == 0) {
+    if (e < ndw) dw[e] = a;
+    else db[e - ndw] = a;
+  }
 }
 
 }  // namespace
@@ -365,7 +378,7 @@ extern "C" int lss_head_ce_bwd(const void* y, const float* head_w, const float* 
     hipLaunchKernelGGL((head_ce_kernel<8, true>), dim3(grid), dim3(256), 0, st, yp, head_w, head_b, target, class_w, M,
                        sums, grad_loss, nullptr, dyp, workspace);
   const int n = K * 128 + K;
-  hipLaunchKernelGGL(head_ce_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, workspace, grid, n, d_head_w,
+  hipLaunchKernelGGL(head_ce_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, st, workspace, grid, n, d_head_w,
                      d_head_b, K * 128);
   return lss_launch_status();
 }
