@@ -26,6 +26,8 @@ int lss_linear_bf16_launch(const void* x, const void* w, const float* scale, con
 
 namespace {
 
+constexpr bool NT_OK(int kh, int kw) { return kh * kw >= 6; }
+
 struct ConvArgs {
   const void* x;
   const void* x2;
@@ -340,9 +342,16 @@ __device__ __forceinline__ void wait_vmcnt() {
 // HEAD: the epilogue reduces the fused 1x1 head instead of storing the activation (its own instantiation: the
 // head and the store path each keep only their own operands live - the store path's residual prefetch and
 // the head's operand fragments together overflowed the 168-register budget of the KC = 32 kernels).
-template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64, int KSP = 1, bool HEAD = false>
-__global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void conv_lds_kernel(ConvArgs a, int tilesX,
-                                                                                             int tilesY) {
+// PFB (fused upsample, KC = 32): the bilinear blend of the NEXT chunk's patch is computed into registers while the
+// last four taps of the current chunk run (its VALU work overlaps their MFMAs), so the chunk boundary is a barrier
+// and three LDS stores instead of a synchronous blend phase that every resident workgroup hits in lockstep.  Costs
+// the third workgroup per CU: the blended pieces and their temporaries do not fit the 168-register budget - and that
+// turned out to cost more than the hidden blend returns (see conv_pfb_on): kept as a switchable variant.
+template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64, int KSP = 1, bool HEAD = false,
+          bool PFB = false>
+__global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : ((KC == 32 && !PFB) ? 3 : 2)) void conv_lds_kernel(
+    ConvArgs a, int tilesX, int tilesY) {
+  static_assert(!PFB || (MODE == 1 && KC == 32 && NT_OK(KH, KW)), "PFB is the fused-upsample, 32-channel-step variant");
   // KSP = 2: intra-workgroup split-K for grids that cannot fill the chip (layer2/layer3: 112-208
   // workgroups of 18-36 latency-bound steps on 256 CUs).  512 threads = two 4-wave groups, each
   // with its own weight ring and patch, each taking half of the input-channel chunks; the second
@@ -542,6 +551,25 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
       *reinterpret_cast<uint4*>(in_tile + py * IROWB + px * POSB + part * 16) = v;
     }
   };
+  // PFB: the same blend for an upsampled chunk whose source pixels sit in src_tile, into ireg[] (fully unrolled:
+  // the pieces must stay in registers until store_in() writes them at the chunk boundary)
+  auto blend_to_regs = [&]() {
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (g_off[i] & 4) {
+        const unsigned char* p00 = src_tile + (g_off[i] & ~15);
+        const int dx = (g_off[i] & 1) ? PPP * 16 : 0, dy = (g_off[i] & 2) ? SRC_W * PPP * 16 : 0;
+        const uint4 q00 = *reinterpret_cast<const uint4*>(p00);
+        const uint4 q01 = *reinterpret_cast<const uint4*>(p00 + dx);
+        const uint4 q10 = *reinterpret_cast<const uint4*>(p00 + dy);
+        const uint4 q11 = *reinterpret_cast<const uint4*>(p00 + dy + dx);
+        v = blend_bf16x8(q00, q01, q10, q11, (float)(g_w[i] & 0xffff) * (1.f / 65536.f),
+                         (float)(g_w[i] >> 16) * (1.f / 65536.f));
+      }
+      ireg[i] = v;
+    }
+  };
 
   // SRC: source pixels of `chunk` -> src_tile (lane l of DMA block k lands at byte k*1024 + l*16)
   auto issue_src = [&](int chunk) {
@@ -693,9 +721,13 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void 
       // counted waits of tap 0 and tap 1 leave them in flight, the wait of tap 2 retires them
       if (SRC && tap == 0 && srcq) issue_src(chunk + 1);
       if (prefetch) gather_in(chunk + 1, false);  // next patch -> registers
+      // PFB: the next chunk's source pixels landed with the wait of tap 2 (see below): blend them into registers now,
+      // under the MFMAs of the remaining taps
+      if (PFB && tap == PF_TAP && srcq) blend_to_regs();
       if (tap == NT - 1 && !last_chunk) {
         lds_barrier();  // every wave is done with this chunk's patch
-        if (FUSED) gather_fused(chunk + 1);
+        if (PFB && srcq) store_in();
+        else if (FUSED) gather_fused(chunk + 1);
         else store_in();
       }
       // W(step+1) must have landed in every wave's share before anyone reads it; only the
@@ -1050,6 +1082,14 @@ inline int conv_src_lds_ok(const ConvArgs& a) {
   return a.up >= 2 && a.ry * 9.f < 4.99f && a.rx * 17.f < 8.99f;
 }
 
+// LSS_CONV_PFB=1 selects the prefetched-blend variant (PFB) of the fused-upsample convs.  Off by default: measured
+// on MI355X (r02, same box A/B) it LOSES - up2.1 126.7 -> 131.9 us, up1.conv0 80.8 -> 87.3 us, step 0.516 -> 0.528 ms:
+// hiding the blend under the MFMAs is worth less than the third co-resident workgroup it costs (226 VGPRs).
+inline bool conv_pfb_on() {
+  const char* e = getenv("LSS_CONV_PFB");
+  return e != nullptr && atoi(e) != 0;
+}
+
 // Tile selection + launch of conv_lds_kernel.  BN = 64 for narrow layers, else 128; RT = 2
 // (throughput shape) unless that grid would leave the 256 CUs under-filled, in which case
 // half-height workgroups (RT = 1) shorten the per-workgroup critical path instead.
@@ -1081,6 +1121,13 @@ void launch_conv_lds(const ConvArgs& a, hipStream_t st) {
         if (kc32) {
           ConvArgs a32 = a;
           a32.src_lds = MODE == 1 ? conv_src_lds_ok(a) : 0;
+          if constexpr (MODE == 1) {
+            if (a32.src_lds && conv_pfb_on()) {
+              hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD, 32, 1, false, true>), g, dim3(256), 0, st, a32,
+                                 tilesX, tilesY);
+              return;
+            }
+          }
           hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD, 32>), g, dim3(256), 0, st, a32, tilesX, tilesY);
           return;
         }
@@ -1321,7 +1368,10 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
   if (const char* e = getenv("LSS_CONV_KC")) kc32 = kc32 && atoi(e) == 32;
   if (fused && kc32) {
     a.src_lds = conv_src_lds_ok(a);
-    hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1, 32, 1, true>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    if (a.src_lds && conv_pfb_on())
+      hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1, 32, 1, true, true>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    else
+      hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1, 32, 1, true>), g, dim3(256), 0, st, a, tilesX, tilesY);
   }
   else if (fused)
     hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1, 64, 1, true>), g, dim3(256), 0, st, a, tilesX, tilesY);
