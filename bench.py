@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--two-streams", action="store_true",
                     help="extra informational leg: the same steps with two batches in flight on two HIP streams")
-    ap.add_argument("--train-steps", type=int, default=8)
+    ap.add_argument("--train-steps", type=int, default=16)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -375,7 +375,7 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     def one():  # ref: train.py:49-66 (zero_grad, forward, loss, backward, clip 5.0, Adam) + the DP all-reduce
         dp.train_step(wrapped, bucket, opt, loss_fn, (feats,) + tuple(calib), clip=5.0)
 
-    for _ in range(2):
+    for _ in range(5):  # MIOpen's first-call kernel selection, Adam state, allocator growth: all outside the timed steps
         one()
     if dist is not None:
         dist.barrier()

@@ -347,10 +347,24 @@ __device__ __forceinline__ void wait_vmcnt() {
 // and three LDS stores instead of a synchronous blend phase that every resident workgroup hits in lockstep.  Costs
 // the third workgroup per CU: the blended pieces and their temporaries do not fit the 168-register budget - and that
 // turned out to cost more than the hidden blend returns (see conv_pfb_on): kept as a switchable variant.
+// LDS bytes of one workgroup of the tile body below (same formulas; the body static_asserts the match)
+template <int RT, int BN, int MODE, int KH, int KW, int KC, int KSP>
+constexpr int conv_lds_smem_bytes() {
+  constexpr int TH = (4 / (BN / 64)) * RT * 2, IW = 16 + KW - 1, IH = TH + KH - 1, POSB = KC * 2 + 16;
+  constexpr int IROWB = (IW * POSB + 255) / 256 * 256, W_BYTES = BN * KC * 2, PPP = KC / 8;
+  constexpr int OUT_BYTES = (TH / (KC == 32 ? 2 : 1)) * 16 * (BN + 4) * 4;
+  constexpr int GROUP_BYTES = (3 * W_BYTES + IH * IROWB + 1023) / 1024 * 1024;
+  constexpr int SRC_DMA = (MODE == 1 && KC == 32) ? (((IH - 1) / 2 + 3) * ((IW - 1) / 2 + 3) * PPP + 255) / 256 : 0;
+  return (KSP * GROUP_BYTES > OUT_BYTES ? KSP * GROUP_BYTES : OUT_BYTES) + SRC_DMA * 4096;
+}
+
+// The tile body: one workgroup's output tile.  bid / nwg: index of the tile in its class and the size of the class
+// (XCD-aware order), nblk_y: index of the BN-wide channel block, oy_base: first image row of the class (the mixed
+// launch below covers the top rows of every image with RT = 2 tiles and the rest with RT = 1 tiles).
 template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64, int KSP = 1, bool HEAD = false,
           bool PFB = false>
-__global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : ((KC == 32 && !PFB) ? 3 : 2)) void conv_lds_kernel(
-    ConvArgs a, int tilesX, int tilesY) {
+__device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int tilesY, int bid, int nwg, int nblk_y,
+                                              int oy_base, unsigned char* smem) {
   static_assert(!PFB || (MODE == 1 && KC == 32 && NT_OK(KH, KW)), "PFB is the fused-upsample, 32-channel-step variant");
   // KSP = 2: intra-workgroup split-K for grids that cannot fill the chip (layer2/layer3: 112-208
   // workgroups of 18-36 latency-bound steps on 256 CUs).  512 threads = two 4-wave groups, each
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : ((KC == 32 && !PFB) ? 3 :
   static_assert(SMEM_BYTES <= (KSP == 2 ? 160 : (KC == 32 ? 53 : 80)) * 1024, "workgroups per CU vs 160 KiB of LDS");
   static_assert(!SRC || NT >= 3, "the source copies retire at tap 2");
   static_assert(KC == 64 || (RT == 2 && BN == 128 && MODE != 2), "KC = 32 is built for the RT = 2, BN = 128 stride-1 tiles");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
+  static_assert(SMEM_BYTES == conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP>(), "conv_lds_smem_bytes out of sync");
   const int grp = KSP == 2 ? (int)(threadIdx.x >> 8) : 0;  // K-split group of this wave
   unsigned char* w_tile = smem + grp * GROUP_BYTES;
   unsigned char* in_tile = w_tile + 3 * W_BYTES;
@@ -410,19 +424,18 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : ((KC == 32 && !PFB) ? 3 :
   // pulling the whole input from the Infinity Cache.  Bijective for any grid size.
   int t;
   {
-    const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   }
   const int tx = t % tilesX; t /= tilesX;
   const int ty = t % tilesY;
   const int b = t / tilesY;
-  const int oy0 = ty * TH, ox0 = tx * TW, n0 = blockIdx.y * BN;
+  const int oy0 = oy_base + ty * TH, ox0 = tx * TW, n0 = nblk_y * BN;
   const int wc = wave % WCOLS, wr = wave / WCOLS;
   const int prow0 = wr * (2 * RT);
   auto stamp = [&](int k) {
     if (a.stamps != nullptr && threadIdx.x == 0)
-      a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = __builtin_amdgcn_s_memrealtime();
+      a.stamps[((size_t)nblk_y * nwg + bid) * 8 + k] = __builtin_amdgcn_s_memrealtime();
   };
   stamp(0);
 
@@ -1032,6 +1045,35 @@ __global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : ((KC == 32 && !PFB) ? 3 :
   }
 }
 
+template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64, int KSP = 1, bool HEAD = false,
+          bool PFB = false>
+__global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : ((KC == 32 && !PFB) ? 3 : 2)) void conv_lds_kernel(
+    ConvArgs a, int tilesX, int tilesY) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP>()];
+  conv_lds_tile<RT, BN, MODE, KH, KW, PAD, KC, KSP, HEAD, PFB>(a, tilesX, tilesY, blockIdx.x, gridDim.x, blockIdx.y, 0,
+                                                              smem);
+}
+
+// Mixed launch for grids that end in a partial round: the first `nfull` workgroups of every channel block are
+// full-height (RT = 2) tiles over image rows [0, oy_split) - exactly whole rounds of the 2 x 256 resident slots -
+// and the rest are half-height (RT = 1) tiles over rows [oy_split, Ho).  The tail then keeps every CU busy with
+// small tiles instead of leaving most of them one big tile short (up1.conv3: 728 tiles on 512 slots = one full
+// round and a 42 %-full one).  1-D grid, full tiles first, so the dispatcher hands the small ones out last.
+template <int BN, int MODE, int KH, int KW, int PAD, int KC, bool HEAD>
+__global__ __launch_bounds__(256, 2) void conv_lds_mixed_kernel(ConvArgs a, int tilesX, int tilesY2, int tilesY1,
+                                                                int nfull, int nhalf, int nblk, int oy_split) {
+  constexpr int B2 = conv_lds_smem_bytes<2, BN, MODE, KH, KW, KC, 1>(), B1 = conv_lds_smem_bytes<1, BN, MODE, KH, KW, KC, 1>();
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[B2 > B1 ? B2 : B1];
+  const int id = blockIdx.x;
+  if (id < nfull * nblk) {
+    conv_lds_tile<2, BN, MODE, KH, KW, PAD, KC, 1, HEAD, false>(a, tilesX, tilesY2, id % nfull, nfull, id / nfull, 0, smem);
+  } else {
+    const int k = id - nfull * nblk;
+    conv_lds_tile<1, BN, MODE, KH, KW, PAD, KC, 1, HEAD, false>(a, tilesX, tilesY1, k % nhalf, nhalf, k / nhalf, oy_split,
+                                                               smem);
+  }
+}
+
 // OIHW fp32 -> [tap][co][ci] in T
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, int Cout, int Cin, int KHW,
@@ -1130,6 +1172,29 @@ void launch_conv_lds(const ConvArgs& a, hipStream_t st) {
           }
           hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD, 32>), g, dim3(256), 0, st, a32, tilesX, tilesY);
           return;
+        }
+      }
+      // LSS_CONV_MIXED=1: a grid that ends in a partial round of the 512 resident slots (2 per CU) gets a mixed launch:
+      // whole rounds of full-height tiles over the top rows of every image, half-height tiles over the rest.  Off by
+      // default - measured on MI355X (r02): up1.conv3 (728 tiles) 64.1 -> 68.8 us stand-alone, 0.5106 -> 0.5111 ms end
+      // to end: the half-height tiles are ~1.6x less efficient per FLOP (weight DMA + barrier per 8 MFMAs), which eats
+      // what the fuller tail returns.  Bitwise the plain launch's result (test_k8_mixed_tile_launch).
+      if constexpr (MODE == 0 && KH == 3) {
+        const long long slots = 512, per_band = (long long)tilesX * a.B * nblk;  // workgroups per full row band
+        const long long rounds = nwg2 / slots, rest = nwg2 - rounds * slots;
+        bool mixed = rounds >= 1 && rest * 10 >= slots && rest * 10 <= slots * 8 && per_band <= slots;
+        const char* emx = getenv("LSS_CONV_MIXED");
+        mixed = mixed && emx != nullptr && atoi(emx) != 0;
+        if (mixed) {
+          const int kf = (int)(rounds * slots / per_band);       // full row bands per image
+          const int oy_split = kf * th2;
+          if (kf >= 1 && oy_split < a.Ho) {
+            const int tilesY1 = lss_cdiv(a.Ho - oy_split, th2 / 2);
+            const int nfull = tilesX * kf * a.B, nhalf = tilesX * tilesY1 * a.B;
+            hipLaunchKernelGGL((conv_lds_mixed_kernel<128, MODE, KH, KW, PAD, 64, false>), dim3((nfull + nhalf) * nblk),
+                               dim3(256), 0, st, a, tilesX, kf, tilesY1, nfull, nhalf, nblk, oy_split);
+            return;
+          }
         }
       }
       hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);

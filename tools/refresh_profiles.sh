@@ -1,16 +1,31 @@
 #!/bin/bash
 # Re-collect the rocprofv3 evidence of profiles/ on the GPU box (run through gpurun from the repo root):
-#   bash tools/refresh_profiles.sh
-# Writes under gpurun_out/prof/; tools/prof_summary.py / tools/pmc_traffic.py turn the CSVs into profiles/r01_*.
-set -e -o pipefail
+#   ROUND=r02 bash tools/refresh_profiles.sh
+# Writes under gpurun_out/prof_$ROUND/; tools/make_profiles.py turns that directory into profiles/$ROUND_*.
+# Counters are collected in their own passes (--kernel-trace + --pmc only), as the pool requires.
+set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$R/gpurun_out/prof
+ROUND=${ROUND:-r02}
+OUT=$R/gpurun_out/prof_$ROUND
 rm -rf "$OUT" && mkdir -p "$OUT"
 ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-train"
-python $R/bench.py --steps 100 --warmup 10 > $OUT/bench_line.json
+cd $R
+python bench.py --steps 100 --warmup 10 > $OUT/bench_line.json 2> $OUT/bench_line.err
+python bench.py --workload hires --steps 50 --warmup 10 --no-train --no-cpu-baseline > $OUT/bench_hires.json 2>/dev/null
+python bench.py --precision fp32 --steps 20 --warmup 5 --no-train --no-cpu-baseline > $OUT/bench_fp32.json 2>/dev/null
+python bench.py --workload config1 --steps 100 --warmup 10 --no-train > $OUT/bench_config1.json 2>/dev/null
+LSS_BENCH_REHEARSE=1 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_rehearse2.txt 2>/dev/null
+python tools/bench_kernels.py --only conv > $OUT/bk_conv.txt 2>&1
+python tools/bench_kernels.py --only stamps > $OUT/bk_stamps.txt 2>&1
+python tools/bench_kernels.py --only l1 > $OUT/bk_l1.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $R/bench.py $ARGS > $OUT/kt.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python $R/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python $R/bench.py $ARGS > $OUT/write.log 2>&1
-find $OUT -name "*.csv" | head -20
-cat $OUT/bench_line.json
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/sq -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-train > $OUT/sq.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_hires -- python $R/bench.py --workload hires $ARGS > $OUT/kt_hires.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_fp32 -- python $R/bench.py --precision fp32 --steps 10 --warmup 3 --no-cpu-baseline --no-train > $OUT/kt_fp32.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_train -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --train-steps 10 > $OUT/kt_train.log 2>&1
+cd $R
+find $OUT -name "*.csv" | wc -l
+tail -c 600 $OUT/bench_line.json
