@@ -328,7 +328,9 @@ int lss_bn_train_bwd(const void* dy, const void* y, const void* z, long long M, 
 /* Split forms for SYNCHRONISED BatchNorm under data parallelism: the per-channel sums
  * come back as a (2, C) fp32 vector, the caller all-reduces it over the ranks, and the second half
  * normalises this rank's rows with the GLOBAL statistics (M_total = rows of all ranks).
- *   lss_bn_partial_sums  mode 0: (sum z, sum z^2);  mode 1: (sum g, sum g*xhat), g = dy masked by ReLU
+ *   lss_bn_partial_sums  mode 0: (sum (z-p), sum (z-p)^2) about the pivot vector p = `mean` (shared by all ranks: the
+ *                        running mean; NULL = 0; pass the same vector as running_mean to _fwd_from_sums - it keeps a
+ *                        large-mean channel's variance from cancelling);  mode 1: (sum g, sum g*xhat), g = dy masked by ReLU
  *   lss_bn_train_fwd_from_sums / _bwd_from_sums: as lss_bn_train_fwd / _bwd with the statistics given.
  *   (_bwd_from_sums writes the GLOBAL sums to dgamma / dbeta; a DP caller keeps its local sums instead.) */
 int lss_bn_partial_sums(const void* z, const void* dy, const void* y, const float* mean, const float* invstd,

@@ -34,14 +34,20 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 }
 
 // per-workgroup partial sums: part[blk][0][c] = sum a, part[blk][1][c] = sum b over the
-// workgroup's rows, where (a, b) = (z, z^2) [MODE 0] or (g, g * xhat) [MODE 1]
+// workgroup's rows, where (a, b) = (z - p, (z - p)^2) [MODE 0] or (g, g * xhat) [MODE 1].
+// MODE 0 sums are taken about a per-channel PIVOT p: var = E[(z-p)^2] - (E[z-p])^2 cancels relative
+// to (mean - p)^2 instead of mean^2, so a channel whose mean dwarfs its spread keeps its variance.  p = the
+// tensor's own first row (pivot16; local statistics: |mean - p| is of the order of the spread) or a vector every
+// rank shares (pivot32 = running_mean; synchronised statistics: the sums of different ranks must add), else 0.
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __restrict__ z,
                                                         const unsigned short* __restrict__ dy,
                                                         const unsigned short* __restrict__ y,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, long long M, int C,
-                                                        int relu, float* __restrict__ part) {
+                                                        int relu, float* __restrict__ part,
+                                                        const float* __restrict__ pivot32 = nullptr,
+                                                        const unsigned short* __restrict__ pivot16 = nullptr) {
   __shared__ float red[2][256][8];
   const int G = C >> 3;            // channel groups of 8
   const int L = 256 / G;           // row lanes
@@ -57,6 +63,11 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
       is[k] = invstd[g * 8 + k];
     }
   }
+  if (MODE == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      mu[k] = pivot32 ? pivot32[g * 8 + k] : (pivot16 ? lss_bf2f(pivot16[g * 8 + k]) : 0.f);
+  }
   if (lane < L) {
     const long long rows_per = (M + gridDim.x - 1) / gridDim.x;
     const long long r0 = (long long)blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
@@ -66,8 +77,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
       if (MODE == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          a[k] += zv[k];
-          b[k] = fmaf(zv[k], zv[k], b[k]);
+          const float d = zv[k] - mu[k];
+          a[k] += d;
+          b[k] = fmaf(d, d, b[k]);
         }
       } else {
         float gv[8], yv[8];
@@ -118,15 +130,18 @@ __global__ void bn_fwd_finalize_kernel(const float* __restrict__ part, int nblk,
                                        float momentum, float* __restrict__ running_mean,
                                        float* __restrict__ running_var, float* __restrict__ scale,
                                        float* __restrict__ shift, float* __restrict__ save_mean,
-                                       float* __restrict__ save_invstd) {
+                                       float* __restrict__ save_invstd, const float* __restrict__ pivot32 = nullptr,
+                                       const unsigned short* __restrict__ pivot16 = nullptr) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per channel
   if (c >= C) return;
   float s1, s2;
   sum_partials(part, nblk, C, c, s1, s2);
   if ((threadIdx.x & 63) != 0) return;
   const float inv_m = 1.f / (float)M;
-  const float mean = s1 * inv_m;
-  const float var = fmaxf(s2 * inv_m - mean * mean, 0.f);
+  const float piv = pivot32 ? pivot32[c] : (pivot16 ? lss_bf2f(pivot16[c]) : 0.f);  // the sums are about this pivot
+  const float dm = s1 * inv_m;
+  const float mean = piv + dm;
+  const float var = fmaxf(s2 * inv_m - dm * dm, 0.f);
   const float invstd = rsqrtf(var + eps);
   save_mean[c] = mean;
   save_invstd[c] = invstd;
@@ -245,9 +260,9 @@ extern "C" int lss_bn_train_fwd(const void* z, const void* residual, long long M
   float* shift = scale + C;
   const unsigned short* zz = static_cast<const unsigned short*>(z);
   hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(nblk), dim3(256), 0, st, zz, nullptr, nullptr, nullptr, nullptr, M, C,
-                     0, part);
+                     0, part, nullptr, zz);  // pivot = the tensor's first row
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(lss_cdiv(C, 4)), dim3(256), 0, st, part, nblk, M, C, gamma, beta,
-                     eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
+                     eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd, nullptr, zz);
   const long long n8 = M * (C / 8);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n8)), dim3(256), 0, st, zz,
                      static_cast<const unsigned short*>(residual), scale, shift, n8, C, relu,
@@ -357,7 +372,9 @@ __global__ void bn_collapse_kernel(const float* __restrict__ part, int nblk, int
 
 }  // namespace
 
-// mode 0: sums = (sum z, sum z^2);  mode 1: sums = (sum g, sum g * xhat) with g = dy * [y > 0] (relu) or dy
+// mode 0: sums = (sum (z - p), sum (z - p)^2) about the pivot p = `mean` (a vector shared by all ranks, e.g. the running
+// mean; NULL = 0) - pass the SAME vector as running_mean to lss_bn_train_fwd_from_sums;
+// mode 1: sums = (sum g, sum g * xhat) with g = dy * [y > 0] (relu) or dy
 extern "C" int lss_bn_partial_sums(const void* z, const void* dy, const void* y, const float* mean,
                                    const float* invstd, long long M, int C, int relu, int mode, void* workspace,
                                    float* sums, void* stream) {
@@ -370,7 +387,7 @@ extern "C" int lss_bn_partial_sums(const void* z, const void* dy, const void* y,
   const unsigned short* zz = static_cast<const unsigned short*>(z);
   if (mode == 0)
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(nblk), dim3(256), 0, st, zz, nullptr, nullptr, nullptr, nullptr, M,
-                       C, 0, part);
+                       C, 0, part, mean, nullptr);
   else
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(nblk), dim3(256), 0, st, zz, static_cast<const unsigned short*>(dy),
                        static_cast<const unsigned short*>(y), mean, invstd, M, C, relu, part);
@@ -390,8 +407,10 @@ extern "C" int lss_bn_train_fwd_from_sums(const void* z, const void* residual, l
   hipStream_t st = lss_stream(stream);
   float* scale = static_cast<float*>(workspace) + (size_t)red_blocks(M) * 2 * C;
   float* shift = scale + C;
+  // `sums` were taken about running_mean (lss_bn_partial_sums mode 0 with mean = running_mean), read before its update
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(lss_cdiv(C, 4)), dim3(256), 0, st, sums, 1, M_total, C, gamma, beta,
-                     eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
+                     eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd, running_mean,
+                     nullptr);
   const long long n8 = M * (C / 8);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n8)), dim3(256), 0, st, static_cast<const unsigned short*>(z),
                      static_cast<const unsigned short*>(residual), scale, shift, n8, C, relu,

@@ -226,7 +226,7 @@ class _SyncBNActFn(torch.autograd.Function):
         zn = _nhwc_bf16(z)
         rn = None if residual is None else _nhwc_bf16(residual)
         g32 = gamma.detach()
-        sums = ops.bn_partial_sums(zn, 0)
+        sums = ops.bn_partial_sums(zn, 0, mean=running_mean)  # sums about the running mean (shared by all ranks)
         world = dist.get_world_size(group)
         dist.all_reduce(sums, group=group)
         m_total = (zn.numel() // zn.shape[-1]) * world  # equal shards (drop_last loaders, ref src/data.py:294)

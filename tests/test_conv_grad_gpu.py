@@ -149,3 +149,33 @@ def test_bn_train_fwd_bwd_vs_torch(C, relu, res):
         assert rel(dres.float().cpu().permute(0, 3, 1, 2), rf.grad) <= 1e-2
     else:
         assert dres is None
+
+
+def test_bn_train_statistics_of_large_mean_channels():
+    """ADVICE r1: batch variance from single-pass fp32 sums must not cancel when |mean| >> spread.  Channels: ordinary;
+    mean 300 / std 2; mean -2000 / std 8 (bf16 keeps ~3 digits: the rounded values are what both sides see); constant
+    1000 (variance exactly 0 -> invstd = rsqrt(eps)).  Reference: fp64 statistics of the same bf16-rounded tensor."""
+    g = torch.Generator().manual_seed(7)
+    B, H, W, C = 4, 100, 100, 64   # 40 000 rows: the size at which E[z^2] - mean^2 lost the variance
+    z = torch.randn(B, H, W, C, generator=g)
+    z[..., 1] = 300.0 + 2.0 * z[..., 1]
+    z[..., 2] = -2000.0 + 8.0 * z[..., 2]
+    z[..., 3] = 1000.0
+    z = z.bfloat16()
+    gamma, beta = torch.ones(C), torch.zeros(C)
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    y, mean, invstd = ops.bn_train_fwd(z.cuda(), gamma.cuda(), beta.cuda(), rm, rv, 0.1, 1e-5, False, None)
+    zd = z.double().reshape(-1, C)
+    m_ref, v_ref = zd.mean(0), zd.var(0, unbiased=False)
+    i_ref = (v_ref + 1e-5).rsqrt()
+    assert float((mean.cpu().double() - m_ref).abs().max() / m_ref.abs().max()) < 1e-6
+    rel = ((invstd.cpu().double() - i_ref).abs() / i_ref)
+    assert float(rel.max()) < 2e-4, rel[:4]
+    assert abs(float(invstd[3]) - 1e-5 ** -0.5) < 1e-2 * 1e-5 ** -0.5  # the constant channel
+    # and the normalised output of the large-mean channels is unit-variance, zero-mean
+    yn = y.float().cpu().reshape(-1, C)
+    assert abs(float(yn[:, 1].std()) - 1.0) < 2e-2 and abs(float(yn[:, 1].mean())) < 2e-2
+    assert abs(float(yn[:, 2].std()) - 1.0) < 2e-2
+    # constant channel: y = z * scale + shift with the folded (scale, shift) = (316, -316 000): one fp32 rounding of a
+    # 3e5-sized product is what is left (torch's (z - mean) * invstd form gives exactly 0)
+    assert float(yn[:, 3].abs().max()) < 0.05
