@@ -723,11 +723,19 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
         // keep the prefetch reads AHEAD of this k-step's MFMAs (hipcc's scheduler would
         // otherwise sink them next to their use and expose the LDS latency again)
         __builtin_amdgcn_sched_barrier(0);
+#ifdef LSS_CONV_SETPRIO
+        // experiment (cdna_hip_programming.md T5, -DLSS_CONV_SETPRIO): matrix work first among the SIMD's waves.
+        // Measured r02, same box: 0.5263 -> 0.5321 ms/step (-1.1 %): off.
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
           acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][0], acc[i][0], 0, 0, 0);
           acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][1], acc[i][1], 0, 0, 0);
         }
+#ifdef LSS_CONV_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (more && s4 < WPT) issue_w1(t2, c2, slot2, s4);
       }
       // after this step's weight pieces, so that (like them) the copies have two steps to land: the
