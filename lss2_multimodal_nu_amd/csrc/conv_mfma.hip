@@ -348,21 +348,21 @@ __device__ __forceinline__ void wait_vmcnt() {
 // the third workgroup per CU: the blended pieces and their temporaries do not fit the 168-register budget - and that
 // turned out to cost more than the hidden blend returns (see conv_pfb_on): kept as a switchable variant.
 // LDS bytes of one workgroup of the tile body below (same formulas; the body static_asserts the match)
-template <int RT, int BN, int MODE, int KH, int KW, int KC, int KSP>
+template <int RT, int BN, int MODE, int KH, int KW, int KC, int KSP, int PSP = 1>
 constexpr int conv_lds_smem_bytes() {
   constexpr int TH = (4 / (BN / 64)) * RT * 2, IW = 16 + KW - 1, IH = TH + KH - 1, POSB = KC * 2 + 16;
   constexpr int IROWB = (IW * POSB + 255) / 256 * 256, W_BYTES = BN * KC * 2, PPP = KC / 8;
-  constexpr int OUT_BYTES = (TH / (KC == 32 ? 2 : 1)) * 16 * (BN + 4) * 4;
-  constexpr int GROUP_BYTES = (3 * W_BYTES + IH * IROWB + 1023) / 1024 * 1024;
+  constexpr int OUT_BYTES = PSP * (TH / (KC == 32 ? 2 : 1)) * 16 * (BN + 4) * 4;
+  constexpr int GROUP_BYTES = (3 * W_BYTES + PSP * IH * IROWB + 1023) / 1024 * 1024;
   constexpr int SRC_DMA = (MODE == 1 && KC == 32) ? (((IH - 1) / 2 + 3) * ((IW - 1) / 2 + 3) * PPP + 255) / 256 : 0;
-  return (KSP * GROUP_BYTES > OUT_BYTES ? KSP * GROUP_BYTES : OUT_BYTES) + SRC_DMA * 4096;
+  return (KSP * GROUP_BYTES > OUT_BYTES ? KSP * GROUP_BYTES : OUT_BYTES) + PSP * SRC_DMA * 4096;
 }
 
 // The tile body: one workgroup's output tile.  bid / nwg: index of the tile in its class and the size of the class
 // (XCD-aware order), nblk_y: index of the BN-wide channel block, oy_base: first image row of the class (the mixed
 // launch below covers the top rows of every image with RT = 2 tiles and the rest with RT = 1 tiles).
 template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64, int KSP = 1, bool HEAD = false,
-          bool PFB = false>
+          bool PFB = false, int PSP = 1>
 __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int tilesY, int bid, int nwg, int nblk_y,
                                               int oy_base, unsigned char* smem) {
   static_assert(!PFB || (MODE == 1 && KC == 32 && NT_OK(KH, KW)), "PFB is the fused-upsample, 32-channel-step variant");
@@ -373,6 +373,12 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   // the main loop at the same workgroup count; barriers stay workgroup-wide (both groups run the
   // same step sequence).
   static_assert(KSP == 1 || (KSP == 2 && KC == 64), "KSP");
+  // PSP = 2 (512 threads): two 4-wave groups compute two vertically adjacent TH x 16 pixel tiles against ONE weight
+  // ring - each group has its own patch and accumulators, the eight waves share the slab DMA (half the pieces each).
+  // Halves the weight bytes streamed into LDS per MFMA: timing-only builds without the weight DMA ran the big
+  // layers 20-31 % faster (up1.conv3 65 -> 45 us), i.e. the DMA stream, not the MFMA issue, is what the 2 x 4-wave
+  // configuration pays for.  One such workgroup per CU (same 8 waves as two plain ones).
+  static_assert(PSP == 1 || (PSP == 2 && KSP == 1 && BN == 128), "PSP");
   // KC = input channels per (chunk, tap) step.  64: the default.  32: half-depth slabs and patch
   // (39 KB of LDS, <= 168 VGPRs) so THREE workgroups share a CU - used for the big stride-1 layers,
   // whose 728 / 1300 tiles then run in one / two full rounds instead of 1.4 / 2.5 on 512 slots.
@@ -387,14 +393,15 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   constexpr int IROWB = (IW * POSB + 255) / 256 * 256;  // 2816 (KC = 64), 1536 (KC = 32)
   constexpr int IN_BYTES = IH * IROWB;
   constexpr int W_BYTES = BN * KC * 2;
-  constexpr int WPT = W_BYTES / 4096;  // LDS-DMA instructions per wave per step (1 KiB each)
+  constexpr int WPT = W_BYTES / 4096 / PSP;  // LDS-DMA instructions per wave per step (1 KiB each)
+  constexpr int NWV = 4 * PSP;                // waves that share one slab
   constexpr int WCOLS = BN / 64;  // waves along the channel axis
   constexpr int IPT = (IH * IW * PPP + 255) / 256;  // 16-B patch pieces per thread per chunk
   constexpr int OLD = BN + 4;  // fp32 row stride of the epilogue's staged output tile
   // the epilogue stages the fp32 output tile in LDS: whole (KC = 64) or in two halves of TH/2 rows
   constexpr int EPH = KC == 32 ? 2 : 1;
-  constexpr int OUT_BYTES = (TH / EPH) * 16 * OLD * 4;
-  constexpr int GROUP_BYTES = (3 * W_BYTES + IN_BYTES + 1023) / 1024 * 1024;  // ring + patch of one 4-wave group
+  constexpr int OUT_BYTES = (TH / EPH) * 16 * OLD * 4;  // per pixel group
+  constexpr int GROUP_BYTES = (3 * W_BYTES + PSP * IN_BYTES + 1023) / 1024 * 1024;  // ring + patch(es) of one K-split group
   // SRC (fused upsample, KC = 32): the low-res pixels a chunk's patch is interpolated from - at most
   // SRC_H x SRC_W source positions for scale factors >= 2 - are copied ONCE per chunk into LDS by
   // LDS-DMA while the previous chunk's taps run, and the 4-corner blend then reads LDS: 2 DMA
@@ -404,16 +411,17 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   constexpr int SRC_H = (IH - 1) / 2 + 3, SRC_W = (IW - 1) / 2 + 3;  // 7 x 11 for the 10 x 18 patch
   constexpr int SRC_DMA = SRC ? (SRC_H * SRC_W * PPP + 255) / 256 : 0;  // DMA instructions per wave per chunk
   constexpr int SRC_BYTES = SRC_DMA * 4096;
-  constexpr int MAIN_BYTES = KSP * GROUP_BYTES > OUT_BYTES ? KSP * GROUP_BYTES : OUT_BYTES;
-  constexpr int SMEM_BYTES = MAIN_BYTES + SRC_BYTES;
-  static_assert(SMEM_BYTES <= (KSP == 2 ? 160 : (KC == 32 ? 53 : 80)) * 1024, "workgroups per CU vs 160 KiB of LDS");
+  constexpr int MAIN_BYTES = KSP * GROUP_BYTES > PSP * OUT_BYTES ? KSP * GROUP_BYTES : PSP * OUT_BYTES;
+  constexpr int SMEM_BYTES = MAIN_BYTES + PSP * SRC_BYTES;
+  static_assert(SMEM_BYTES <= (KSP * PSP == 2 ? 160 : (KC == 32 ? 53 : 80)) * 1024, "workgroups per CU vs 160 KiB of LDS");
   static_assert(!SRC || NT >= 3, "the source copies retire at tap 2");
   static_assert(KC == 64 || (RT == 2 && BN == 128 && MODE != 2), "KC = 32 is built for the RT = 2, BN = 128 stride-1 tiles");
-  static_assert(SMEM_BYTES == conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP>(), "conv_lds_smem_bytes out of sync");
+  static_assert(SMEM_BYTES == conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP, PSP>(), "conv_lds_smem_bytes out of sync");
   const int grp = KSP == 2 ? (int)(threadIdx.x >> 8) : 0;  // K-split group of this wave
+  const int pgr = PSP == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;  // pixel group of this wave
   unsigned char* w_tile = smem + grp * GROUP_BYTES;
-  unsigned char* in_tile = w_tile + 3 * W_BYTES;
-  unsigned char* src_tile = smem + MAIN_BYTES;  // SRC only
+  unsigned char* in_tile = w_tile + 3 * W_BYTES + pgr * IN_BYTES;
+  unsigned char* src_tile = smem + MAIN_BYTES + pgr * SRC_BYTES;  // SRC only
 
   const int tid = threadIdx.x & 255, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -430,7 +438,8 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   const int tx = t % tilesX; t /= tilesX;
   const int ty = t % tilesY;
   const int b = t / tilesY;
-  const int oy0 = oy_base + ty * TH, ox0 = tx * TW, n0 = nblk_y * BN;
+  const int oy0 = oy_base + (ty * PSP + pgr) * TH, ox0 = tx * TW, n0 = nblk_y * BN;
+  const int dwave = wave + 4 * pgr;  // index among the waves that share the weight ring
   const int wc = wave % WCOLS, wr = wave / WCOLS;
   const int prow0 = wr * (2 * RT);
   auto stamp = [&](int k) {
@@ -469,7 +478,7 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
     const int tap = step % NT, chunk = cbase + step / NT;
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
-      const int blk = i * 4 + wave;
+      const int blk = i * NWV + dwave;
       const int row = KC == 64 ? blk * 8 + (lane >> 3) : blk * 16 + (lane >> 2);
       const int part = KC == 64 ? (lane & 7) ^ ((row >> 1) & 7) : (lane & 3) ^ ((row >> 2) & 3);
       const int co = min(n0 + row, a.Cout - 1);  // rows past Cout: any valid address (never stored)
@@ -647,12 +656,30 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
 
   // one 1-KiB LDS-DMA block of the slab of `step` (block index i of this wave)
   auto issue_w1 = [&](int tap, int chunk, int slot, int i) {
-    const int blk = i * 4 + wave;
+    const int blk = i * NWV + dwave;
     const int row = KC == 64 ? blk * 8 + (lane >> 3) : blk * 16 + (lane >> 2);
     const int part = KC == 64 ? (lane & 7) ^ ((row >> 1) & 7) : (lane & 3) ^ ((row >> 2) & 3);
     const int co = min(n0 + row, a.Cout - 1);
+#if defined(LSS_CONV_DIAG_NOW)
+    // timing-only build: no weight traffic at all (results are garbage)
+#elif defined(LSS_CONV_DIAG_WQUARTER)
+    // timing-only build: a quarter of the pieces (the first of each wave's WPT)
+    if (i == 0)
+      glds16(wg + ((size_t)tap * a.Cout + co) * a.Cin + (cbase + chunk) * KC + part * 8,
+             w_tile + slot * W_BYTES + blk * 1024);
+#elif defined(LSS_CONV_DIAG_WVGPR)
+    // timing-only build: the same 16 B per lane fetched into a register instead of LDS (no LDS write, same requests)
+    {
+      const uint4 v = *reinterpret_cast<const uint4*>(wg + ((size_t)tap * a.Cout + co) * a.Cin + (cbase + chunk) * KC + part * 8);
+      asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+    }
+#elif defined(LSS_CONV_DIAG_WSAME)
+    // timing-only build: every step re-reads the slab of (tap 0, chunk 0) - same issue count, L1/L2-hot source
+    glds16(wg + ((size_t)0 * a.Cout + co) * a.Cin + part * 8, w_tile + slot * W_BYTES + blk * 1024);
+#else
     glds16(wg + ((size_t)tap * a.Cout + co) * a.Cin + (cbase + chunk) * KC + part * 8,
            w_tile + slot * W_BYTES + blk * 1024);
+#endif
   };
 
   // per-lane epilogue constants, fetched now so their latency is long gone by the epilogue
@@ -768,7 +795,7 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   // Instead: scale/shift in registers -> fp32 tile in LDS (the ring + patch area is
   // free now) -> every thread picks up 8 consecutive channels of a pixel, adds the
   // residual (one 16-B load), ReLU, rounds to bf16 once, and stores 16 B.
-  float* otile = reinterpret_cast<float*>(smem);
+  float* otile = reinterpret_cast<float*>(smem + pgr * OUT_BYTES);
   stamp(2);
   // (the loop's final lds_barrier already guarantees every wave is done reading LDS)
   if (KSP == 2) {
@@ -1054,12 +1081,12 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
 }
 
 template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64, int KSP = 1, bool HEAD = false,
-          bool PFB = false>
-__global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : ((KC == 32 && !PFB) ? 3 : 2)) void conv_lds_kernel(
+          bool PFB = false, int PSP = 1>
+__global__ __launch_bounds__(256 * KSP * PSP, KSP * PSP == 2 ? 1 : ((KC == 32 && !PFB) ? 3 : 2)) void conv_lds_kernel(
     ConvArgs a, int tilesX, int tilesY) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP>()];
-  conv_lds_tile<RT, BN, MODE, KH, KW, PAD, KC, KSP, HEAD, PFB>(a, tilesX, tilesY, blockIdx.x, gridDim.x, blockIdx.y, 0,
-                                                              smem);
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP, PSP>()];
+  conv_lds_tile<RT, BN, MODE, KH, KW, PAD, KC, KSP, HEAD, PFB, PSP>(a, tilesX, tilesY, blockIdx.x, gridDim.x,
+                                                                   blockIdx.y, 0, smem);
 }
 
 // Mixed launch for grids that end in a partial round: the first `nfull` workgroups of every channel block are
@@ -1146,7 +1173,8 @@ inline bool conv_pfb_on() {
 template <int MODE, int KH, int KW, int PAD>
 void launch_conv_lds(const ConvArgs& a, hipStream_t st) {
   const int tilesX = lss_cdiv(a.Wo, 16);
-  const bool narrow = a.Cout <= 64;
+  bool narrow = a.Cout <= 64;
+  if (const char* e = getenv("LSS_CONV_BN64")) narrow = narrow || (atoi(e) != 0 && MODE == 0 && a.Cout % 64 == 0);
   const int th2 = narrow ? 16 : 8;
   const int nblk = lss_cdiv(a.Cout, narrow ? 64 : 128);
   const long long nwg2 = (long long)tilesX * lss_cdiv(a.Ho, th2) * a.B * nblk;
@@ -1203,6 +1231,22 @@ void launch_conv_lds(const ConvArgs& a, hipStream_t st) {
                                dim3(256), 0, st, a, tilesX, kf, tilesY1, nfull, nhalf, nblk, oy_split);
             return;
           }
+        }
+      }
+      // Pixel-split pairs (PSP = 2): one 512-thread workgroup = two stacked 8 x 16 tiles on one weight ring.
+      if constexpr (MODE == 0 && KH == 3) {
+        // Off by default - measured on MI355X (r02, same box): up1.conv3 64.6 -> 72.4 us, step 0.501 -> 0.510 ms.  The
+        // weight traffic halves, but 100 rows cut into 16-row pairs waste 12 % of the tile rows (8-row tiles: 4 %) and
+        // eight waves in lockstep on one barrier hide each other's waits worse than two independent 4-wave groups.
+        // (Tall 16 x 16 x 64-channel tiles, LSS_CONV_BN64=1, share a slab the same way with 4-wave barriers: 64.3 ->
+        // 75.1 us, same row waste.)  Bitwise the plain launch's result.
+        const char* epsp = getenv("LSS_CONV_PSP");
+        const bool psp = nwg2 >= 512 && epsp != nullptr && atoi(epsp) != 0;
+        if (psp) {
+          const int tilesYp = lss_cdiv(a.Ho, 2 * th2);
+          hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD, 64, 1, false, false, 2>),
+                             dim3(tilesX * tilesYp * a.B, nblk), dim3(512), 0, st, a, tilesX, tilesYp);
+          return;
         }
       }
       hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);

@@ -174,5 +174,88 @@ __device__ __forceinline__ void depthnet_softmax_f32_body(
   depthnet_epilogue<NT>(acc, lds, bias, bias + D, D, true, bn, pix0, HW, D, C, depth, feat, wg_absmax);
 }
 
+// The same product with the OUTPUT ROWS split over two workgroups per pixel tile (the region pipeline's K2):
+// `rows` logit rows starting at weight row `row0` - the D depth bins (softmax, -> depth) or the C context
+// channels (-> feat, max |feature|).  Against the body above: (i) a workgroup streams only its own rows of W
+// (105 or 110 KB instead of 215 KB through one CU's L1), twice as many workgroups share the chip (2 per CU) and
+// the softmax runs beside the feature stores instead of after them; (ii) a K block is 32 deep: a lane loads 32
+// contiguous bytes of its weight row, the four lane groups of a row cover one whole 128-B line per load, where the
+// 16-deep block fetched every line in two halves 7 tile-loads apart (a 57 KB working set per block against the
+// 32 KB L1: most lines came from L2 twice).  Per accumulator the k order is (kb + 8 j + s), j = lane group, s = 0..7:
+// fixed, so results are reproducible; they differ from the 16-deep body's in the last ulp (different association).
+template <int NT>
+__device__ __forceinline__ void depthnet_rows_f32_body(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int row0, int rows,
+    bool is_depth, int Cin, int HW, int D, int C, float* __restrict__ depth, float* __restrict__ feat, int tile_x,
+    int bn, float* lds, float* wg_absmax, unsigned long long* stamps = nullptr) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, j = lane >> 4;
+  const int pix0 = tile_x * PIX;
+  const int pix = min(pix0 + col, HW - 1);
+  const int kq = Cin >> 2;  // K quarter of this wave
+  const float* xb = x + ((size_t)bn * Cin + (size_t)wave * kq + 8 * j) * HW + pix;
+  const float* wb = w + (size_t)row0 * Cin + (size_t)wave * kq + 8 * j;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto load_block = [&](int kb, float (&xs)[8], f32x4 (&wa)[NT][2]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) xs[s] = xb[(size_t)(kb + s) * HW];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = 16 * t + col;
+      wa[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      wa[t][1] = wa[t][0];
+      if (n < rows) {
+        wa[t][0] = *reinterpret_cast<const f32x4*>(wb + (size_t)n * Cin + kb);
+        wa[t][1] = *reinterpret_cast<const f32x4*>(wb + (size_t)n * Cin + kb + 4);
+      }
+    }
+  };
+  auto mma_block = [&](const float (&xs)[8], const f32x4 (&wa)[NT][2]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t][s >> 2][s & 3], xs[s], acc[t], 0, 0, 0);
+  };
+  const int nblk = kq >> 5;
+  // In-kernel stamps (tools/bench_l1.py --stamps): a workgroup is ~2.3 us to its first operands, ~1.5-2 us per further
+  // K block (the 528 workgroups together pull ~75 MB through the L1s in ~8 us: the launch sits at the L2 -> L1 rate
+  // this access pattern reaches, ~9 TB/s), 2.5 us of epilogue.  Requesting all four K blocks of the LSS depthnet's K
+  // quarter before the first MFMA shortens a workgroup by ~2 us but needs 180 registers = 2 waves per SIMD = 512
+  // workgroup slots for 528 workgroups: the 16 left over start when a first-round workgroup retires, and the launch
+  // ends later than before (level 48.9 -> 51.1 us).
+  {
+    // two operand sets: the next K block is in flight behind the one being multiplied.  (A third set - two blocks in
+    // flight - does not fit the 168-register budget of 3 waves per SIMD: 178 spilled registers.)
+    float xs0[8], xs1[8];
+    f32x4 wa0[NT][2], wa1[NT][2];
+    load_block(0, xs0, wa0);
+    if (stamps != nullptr) {  // diagnostic runs only: first operands landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
+    }
+    int i = 0;
+    for (; i + 2 <= nblk; i += 2) {
+      load_block((i + 1) << 5, xs1, wa1);
+      mma_block(xs0, wa0);
+      if (i + 2 < nblk) load_block((i + 2) << 5, xs0, wa0);
+      mma_block(xs1, wa1);
+    }
+    if (i < nblk) mma_block(xs0, wa0);
+  }
+  if (stamps != nullptr && threadIdx.x == 0) {
+    asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[NT - 1][3]));  // the MFMA chain has retired
+    stamps[2] = __builtin_amdgcn_s_memrealtime();
+  }
+
+  if (is_depth)
+    depthnet_epilogue<NT>(acc, lds, bias, bias, NT * 16, true, bn, pix0, HW, D, 0, depth, feat, nullptr);
+  else
+    depthnet_epilogue<NT>(acc, lds, bias, bias + D, 0, false, bn, pix0, HW, 0, C, depth, feat, wg_absmax);
+}
 
 }  // namespace lss_depthnet

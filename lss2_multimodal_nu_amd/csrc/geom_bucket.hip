@@ -170,6 +170,8 @@ struct FusedK2K3Args {
   // region bucketing (use_regions != 0): K3 blocks count per region in LDS instead of per voxel in global
   // memory, K2 blocks leave their max |feature|
   int use_regions;
+  unsigned long long* stamps;  // LSS_L1_STAMPS=<hex device address, 8 u64 per workgroup>: s_memrealtime phase stamps
+  int diag;  // timing-only builds (LSS_K2K3_DIAG): 1 = the K2 blocks return at once, 2 = the K3 blocks do
   RegionArgs rg;
 };
 
@@ -200,6 +202,45 @@ __global__ __launch_bounds__(256) void depthnet_and_voxels_hostcal_kernel(FusedK
     const int k = id - a.n2;
     points_to_voxels_body(a.frustum, cal, a.dx, a.bx, a.Ncam, a.DHW, a.X, a.Y, a.Z, a.voxel, a.vox_count, nullptr,
                           k % a.gx3, k / a.gx3, a.use_regions ? reinterpret_cast<int*>(lds) : nullptr, &a.rg);
+  }
+}
+
+// Region pipeline: K2 with its output rows split over two workgroups per pixel tile (depthnet_rows_f32_body).  Blocks
+// [0, n2x) are K2's ((tile, half), half 0 = the D depth bins + softmax, half 1 = the C context channels): the long
+// ones (~10-13 us) go first, ALL of them resident at once - 3 waves per SIMD = 768 workgroup slots for the 528 - and
+// the short geometry workgroups (K3, ~2 us each) flow through the slots that are left.  In-kernel stamps
+// (tools/bench_l1.py --stamps) showed what the other arrangements cost: with 2 waves per SIMD (512 slots) 16 of the
+// K2 workgroups started only when a first-round one retired (launch end 20 us instead of 14) and the geometry
+// started 14 us in; with the geometry first every K2 workgroup started 3 us late.
+template <int ND, int NC, bool HOSTCAL>
+__global__ __launch_bounds__(256, 3) void depthnet_rows_and_voxels_kernel(FusedK2K3Args a, CalInline cal, int n2x) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int id = blockIdx.x;
+  if (a.diag != 0 && (id < n2x) == (a.diag == 1)) return;
+  unsigned long long* st = a.stamps ? a.stamps + (size_t)id * 8 : nullptr;
+  if (st != nullptr && threadIdx.x == 0) st[0] = __builtin_amdgcn_s_memrealtime();
+  if (id < n2x) {
+    const int k2 = id, tile = k2 >> 1;
+    if ((k2 & 1) == 0)
+      lss_depthnet::depthnet_rows_f32_body<ND>(a.x, a.w, a.bias, 0, a.D, true, a.Cin, a.HW, a.D, a.C, a.depth, a.feat,
+                                               tile % a.gx2, tile / a.gx2, lds, nullptr, st);
+    else
+      lss_depthnet::depthnet_rows_f32_body<NC>(a.x, a.w, a.bias, a.D, a.C, false, a.Cin, a.HW, a.D, a.C, a.depth,
+                                               a.feat, tile % a.gx2, tile / a.gx2, lds, a.rg.wg_absmax + tile, st);
+  } else {
+    const int k = id - n2x;
+    if (HOSTCAL) {
+      points_to_voxels_body(a.frustum, cal, a.dx, a.bx, a.Ncam, a.DHW, a.X, a.Y, a.Z, a.voxel, a.vox_count, nullptr,
+                            k % a.gx3, k / a.gx3, reinterpret_cast<int*>(lds), &a.rg);
+    } else {
+      const CalPtr calp = {a.inv_post_rots, a.post_trans, a.combine, a.trans};
+      points_to_voxels_body(a.frustum, calp, a.dx, a.bx, a.Ncam, a.DHW, a.X, a.Y, a.Z, a.voxel, a.vox_count, nullptr,
+                            k % a.gx3, k / a.gx3, reinterpret_cast<int*>(lds), &a.rg);
+    }
+  }
+  if (st != nullptr) {
+    __syncthreads();
+    if (threadIdx.x == 0) st[3] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -494,6 +535,9 @@ static int depthnet_voxels_impl(const float* frustum, const float* inv_post_rots
   a.trans = trans; a.dx = dx; a.bx = bx; a.Ncam = N; a.DHW = (int)DHW; a.X = X; a.Y = Y; a.Z = Z;
   a.voxel = voxel; a.vox_count = vox_count;
   a.use_regions = plan != nullptr;
+  a.diag = getenv("LSS_K2K3_DIAG") ? atoi(getenv("LSS_K2K3_DIAG")) : 0;
+  a.stamps = getenv("LSS_L1_STAMPS") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("LSS_L1_STAMPS"), nullptr, 16))
+                                     : nullptr;
   if (plan != nullptr) {
     if (plan->n2 != a.n2 || plan->rps != plan->nRx * plan->nRy) return LSS_E_WORKSPACE;
     a.rg.region_count = plan->region_count; a.rg.region_cursor = plan->region_cursor;
@@ -514,6 +558,20 @@ static int depthnet_voxels_impl(const float* frustum, const float* inv_post_rots
   if (calib_host != nullptr) {
     cal.n = B * N;
     for (int i = 0; i < B * N * 24; ++i) cal.v[i] = calib_host[i];
+  }
+  // the row-split K2 (region pipeline, the shapes of the LSS depthnet: D <= 48, C <= 64, Cin a multiple of 128)
+  static const bool rows_off = getenv("LSS_K2_ROWS") != nullptr && atoi(getenv("LSS_K2_ROWS")) == 0;
+  if (plan != nullptr && !rows_off && (D + 15) / 16 == 3 && (C + 15) / 16 == 4 && Cin % 128 == 0 &&
+      ((size_t)D * Cin * sizeof(float)) % 16 == 0) {
+    const long long nb = nblk + a.n2;
+    if (nb >= (1LL << 31)) return LSS_E_SHAPE;
+    size_t lb = (size_t)5 * 4 * 16 * lss_depthnet::LDS_LD * sizeof(float);
+    if ((size_t)plan->rps * sizeof(int) > lb) lb = (size_t)plan->rps * sizeof(int);
+    if (calib_host != nullptr)
+      hipLaunchKernelGGL((depthnet_rows_and_voxels_kernel<3, 4, true>), dim3((unsigned)nb), dim3(256), lb, st, a, cal, 2 * a.n2);
+    else
+      hipLaunchKernelGGL((depthnet_rows_and_voxels_kernel<3, 4, false>), dim3((unsigned)nb), dim3(256), lb, st, a, cal, 2 * a.n2);
+    return lss_launch_status();
   }
 #define LSS_F_CASE(n)                                                                                          \
   case n:                                                                                                      \

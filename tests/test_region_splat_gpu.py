@@ -98,8 +98,11 @@ def test_region_pipeline_vs_fp64_and_voxel_list_pipeline(ops, monkeypatch, case,
     bev_l, depth_l, feat_l, ws_l = run(ops, pr, layout, True, monkeypatch)
     X, Y, Z = pr["nx"]
     assert tuple(bev.shape) == (B, Z * C, X, Y)
-    # same K2 / K3 kernels in both pipelines
-    assert torch.equal(depth, depth_l) and torch.equal(feat, feat_l) and torch.equal(ws.voxel, ws_l.voxel)
+    # same K3 arithmetic in both pipelines (exact ids); the region pipeline's K2 splits the output rows over two
+    # workgroups and walks K in 32-deep blocks: the same fp32 products, associated differently (last-ulp differences)
+    assert torch.equal(ws.voxel, ws_l.voxel)
+    torch.testing.assert_close(depth, depth_l, rtol=2e-5, atol=1e-7)
+    torch.testing.assert_close(feat, feat_l, rtol=2e-5, atol=2e-5 * float(feat_l.abs().max()))
     ref, idx, kept = oracle_bev(pr, depth, feat)
     # voxel ids: exact against the oracle
     vid = np.where(kept, ((np.broadcast_to(np.arange(B).reshape(B, 1, 1, 1, 1), kept.shape) * X + idx[..., 0]) * Y

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--hires", action="store_true")
     ap.add_argument("--modes", default="legacy,0")
+    ap.add_argument("--stamps", action="store_true", help="s_memrealtime phase stamps of the fused K2 || K3 launch")
     args = ap.parse_args()
     B = args.batch
     grid = dict(xbound=[-50.0, 50.0, 0.5], ybound=[-50.0, 50.0, 0.5], zbound=[-10.0, 10.0, 20.0], dbound=[4.0, 45.0, 1.0])
@@ -34,6 +35,37 @@ def main():
     def step():
         return m._lift_splat(x, *calib, ops.BEV_NHWC_BF16)
 
+    if args.stamps:
+        import numpy as np
+        n2 = -(-fH * fW // 16) * B * 6
+        with torch.no_grad():
+            for _ in range(5):
+                step()
+            buf = torch.zeros(16384 * 8, dtype=torch.int64, device="cuda")
+            os.environ["LSS_L1_STAMPS"] = "%x" % buf.data_ptr()
+            for _ in range(3):
+                buf.zero_()
+                torch.cuda.synchronize()
+                step()
+                torch.cuda.synchronize()
+            del os.environ["LSS_L1_STAMPS"]
+        t = buf.view(-1, 8).cpu().numpy().astype(np.float64) * 0.01  # us
+        live = t[:, 0] != 0
+        t0 = t[live, 0].min()
+        ids = np.arange(len(t))
+        f = lambda v: "p50 %5.2f  p90 %5.2f  max %5.2f" % (np.median(v), np.percentile(v, 90), v.max())
+        for name, sel in (("K2 depth rows", live & (ids < 2 * n2) & (ids % 2 == 0)),
+                          ("K2 context rows", live & (ids < 2 * n2) & (ids % 2 == 1)), ("K3 geometry", live & (ids >= 2 * n2))):
+            q = t[sel]
+            print("%-16s %5d workgroups" % (name, len(q)))
+            print("   start after launch   %s" % f(q[:, 0] - t0))
+            if name != "K3 geometry":
+                print("   first K block landed %s" % f(q[:, 1] - q[:, 0]))
+                print("   K loop               %s" % f(q[:, 2] - q[:, 1]))
+                print("   epilogue             %s" % f(q[:, 3] - q[:, 2]))
+            print("   whole workgroup      %s" % f(q[:, 3] - q[:, 0]))
+            print("   end after launch     %s" % f(q[:, 3] - t0))
+        return
     for mode in args.modes.split(","):
         os.environ.pop("LSS_SPLAT_LEGACY", None)
         os.environ.pop("LSS_RS_DBG", None)
