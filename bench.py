@@ -137,8 +137,9 @@ def main():
     ap.add_argument("--dry-launch", action="store_true", help="launcher / rendezvous check on the CPU (gloo), no GPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
-    ap.add_argument("--two-streams", action="store_true",
-                    help="extra informational leg: the same steps with two batches in flight on two HIP streams")
+    ap.add_argument("--two-streams", action=argparse.BooleanOptionalAction, default=True,
+                    help="extra informational leg (levels.two_batches_in_flight_fps): the same steps with two batches in "
+                         "flight on two HIP streams; `value` stays the single-stream loop")
     ap.add_argument("--train-steps", type=int, default=16)
     args = ap.parse_args()
 
@@ -272,8 +273,8 @@ def main():
     fps = frames / dt
 
     # ---- roofline of the dominant kernel(s), from the HIP-event brackets -----------------
-    n_conv, ms_conv = spans.get("bevencode", (0, 0.0))   # one bracket per step around the 18 conv launches
-    n_spl, ms_spl = spans.get("lift_splat_level", (0, 0.0))   # one bracket around K3, K2, K4 (2 launches), K5
+    n_conv, ms_conv = spans.get("bevencode", (0, 0.0))   # one bracket per step around the 16 conv launches
+    n_spl, ms_spl = spans.get("lift_splat_level", (0, 0.0))   # one bracket around K2 || K3, region_fill, region_splat
     conv_flops_step = bevencode_flops(X, Y) * B
     peak_tf = MFMA_BF16_TFLOPS if args.precision == "bf16" else MFMA_F32_TFLOPS
     conv_tf = conv_flops_step * args.steps / (ms_conv * 1e-3) / 1e12 if ms_conv else 0.0
@@ -283,7 +284,7 @@ def main():
     splat_bytes_step = l1_bytes_step
     spl_gbs = splat_bytes_step * args.steps / (ms_spl * 1e-3) / 1e9 if ms_spl else 0.0
 
-    conv_traffic, splat_traffic = pmc_traffic("conv_"), pmc_traffic("lift_splat_fwd_kernel")
+    conv_traffic, splat_traffic = pmc_traffic("conv_"), pmc_traffic("region_splat_kernel")
     out = {
         "metric": "BEV frames/sec (6-cam 352x128 -> 200x200x64), full hot path: CamEncode lift + splat + BevEncode",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -301,19 +302,19 @@ def main():
                                          "-> BevEncode -> 400x400x4" % B}[args.workload],
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d (sample-sharded, no collective)" % world,
                    "precision": args.precision, "calibration": "CPU tensors per step; 3x3 inverses on host (exact-index contract), 576 floats passed in the kernel arguments (no H2D copy)"},
-        "roofline": {"kernel": "conv_lds_kernel (+3 conv_direct_kernel): the 18 BevEncode launches of a step, one HIP-event "
+        "roofline": {"kernel": "conv_lds_kernel: the 16 BevEncode launches of a step (stride-2 convs carry their 1x1 downsample, up2 its head), one HIP-event "
                                "bracket around the group (per-launch brackets cost ~10 us of idle each)",
                      "bound": "mfma", "achieved": conv_tf, "peak": peak_tf, "unit": "TFLOP/s",
                      "frac": conv_tf / peak_tf, "traffic": conv_traffic[0], "traffic_unit": "HBM bytes per launch (PMC)",
-                     "traffic_source": conv_traffic[1], "launches": n_conv * 18,
-                     "avg_us": ms_conv * 1e3 / max(n_conv * 18, 1), "flops_per_step": conv_flops_step},
-        "roofline_l1": {"kernel": "lift-splat level = points_to_voxels + depthnet_softmax + bucket_alloc + bucket_fill + "
-                                  "lift_splat_fwd (5 launches, one HIP-event bracket); `traffic` is lift_splat_fwd_kernel's own",
+                     "traffic_source": conv_traffic[1], "launches": n_conv * 16,
+                     "avg_us": ms_conv * 1e3 / max(n_conv * 16, 1), "flops_per_step": conv_flops_step},
+        "roofline_l1": {"kernel": "lift-splat level = depthnet_rows_and_voxels (K2 || K3) + region_fill + region_splat "
+                                  "(3 launches, one HIP-event bracket); `traffic` is region_splat_kernel's own",
                         "bound": "hbm", "achieved": spl_gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": spl_gbs / HBM_PEAK_GBS, "traffic": splat_traffic[0],
                         "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": splat_traffic[1],
-                        "launches": n_spl * 5,
-                        "avg_us": ms_spl * 1e3 / max(n_spl * 5, 1), "level_us": ms_spl * 1e3 / max(n_spl, 1),
+                        "launches": n_spl * 3,
+                        "avg_us": ms_spl * 1e3 / max(n_spl * 3, 1), "level_us": ms_spl * 1e3 / max(n_spl, 1),
                         "bytes_per_step": splat_bytes_step},
         "per_rank_fps": per_rank, "comm": comm,
         "levels": {"L2_hot_path_fps": fps,
