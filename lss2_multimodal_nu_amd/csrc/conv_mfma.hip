@@ -348,10 +348,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // the third workgroup per CU: the blended pieces and their temporaries do not fit the 168-register budget - and that
 // turned out to cost more than the hidden blend returns (see conv_pfb_on): kept as a switchable variant.
 // LDS bytes of one workgroup of the tile body below (same formulas; the body static_asserts the match)
-template <int RT, int BN, int MODE, int KH, int KW, int KC, int KSP, int PSP = 1>
+template <int RT, int BN, int MODE, int KH, int KW, int KC, int KSP, int PSP = 1, int TPS = 1>
 constexpr int conv_lds_smem_bytes() {
   constexpr int TH = (4 / (BN / 64)) * RT * 2, IW = 16 + KW - 1, IH = TH + KH - 1, POSB = KC * 2 + 16;
-  constexpr int IROWB = (IW * POSB + 255) / 256 * 256, W_BYTES = BN * KC * 2, PPP = KC / 8;
+  constexpr int IROWB = (IW * POSB + 255) / 256 * 256, W_BYTES = TPS * BN * KC * 2, PPP = KC / 8;
   constexpr int OUT_BYTES = PSP * (TH / (KC == 32 ? 2 : 1)) * 16 * (BN + 4) * 4;
   constexpr int GROUP_BYTES = (3 * W_BYTES + PSP * IH * IROWB + 1023) / 1024 * 1024;
   constexpr int SRC_DMA = (MODE == 1 && KC == 32) ? (((IH - 1) / 2 + 3) * ((IW - 1) / 2 + 3) * PPP + 255) / 256 : 0;
@@ -362,7 +362,7 @@ constexpr int conv_lds_smem_bytes() {
 // (XCD-aware order), nblk_y: index of the BN-wide channel block, oy_base: first image row of the class (the mixed
 // launch below covers the top rows of every image with RT = 2 tiles and the rest with RT = 1 tiles).
 template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64, int KSP = 1, bool HEAD = false,
-          bool PFB = false, int PSP = 1>
+          bool PFB = false, int PSP = 1, int TPS = 1>
 __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int tilesY, int bid, int nwg, int nblk_y,
                                               int oy_base, unsigned char* smem) {
   static_assert(!PFB || (MODE == 1 && KC == 32 && NT_OK(KH, KW)), "PFB is the fused-upsample, 32-channel-step variant");
@@ -379,6 +379,10 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   // layers 20-31 % faster (up1.conv3 65 -> 45 us), i.e. the DMA stream, not the MFMA issue, is what the 2 x 4-wave
   // configuration pays for.  One such workgroup per CU (same 8 waves as two plain ones).
   static_assert(PSP == 1 || (PSP == 2 && KSP == 1 && BN == 128), "PSP");
+  // TPS = taps per step.  2: a step is TWO taps against a double slab - half the steps (barrier + counted wait + slot
+  // hand-over each) per chunk.  For the 7x7 / 2 stem, whose 64 steps carry only 8 MFMAs per wave each: phase stamps put
+  // a step at 0.43 us against 0.13 us of MFMA issue.  Needs an even tap count and the 24 KB more LDS (BN = 64 only).
+  static_assert(TPS == 1 || (TPS == 2 && (KH * KW) % 2 == 0 && KSP == 1 && PSP == 1 && MODE != 1 && !PFB), "TPS");
   // KC = input channels per (chunk, tap) step.  64: the default.  32: half-depth slabs and patch
   // (39 KB of LDS, <= 168 VGPRs) so THREE workgroups share a CU - used for the big stride-1 layers,
   // whose 728 / 1300 tiles then run in one / two full rounds instead of 1.4 / 2.5 on 512 slots.
@@ -389,10 +393,12 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   constexpr int TH = (4 / (BN / 64)) * RT * 2;  // image rows per workgroup
   constexpr bool FUSED = MODE == 1;
   constexpr int NT = KH * KW;
+  constexpr int NS = NT / TPS;  // steps per chunk
   constexpr int TW = 16, IW = TW + KW - 1, IH = TH + KH - 1, POSB = KC * 2 + 16;
   constexpr int IROWB = (IW * POSB + 255) / 256 * 256;  // 2816 (KC = 64), 1536 (KC = 32)
   constexpr int IN_BYTES = IH * IROWB;
-  constexpr int W_BYTES = BN * KC * 2;
+  constexpr int W1_BYTES = BN * KC * 2;      // slab of one tap
+  constexpr int W_BYTES = TPS * W1_BYTES;    // slab of one step
   constexpr int WPT = W_BYTES / 4096 / PSP;  // LDS-DMA instructions per wave per step (1 KiB each)
   constexpr int NWV = 4 * PSP;                // waves that share one slab
   constexpr int WCOLS = BN / 64;  // waves along the channel axis
@@ -416,7 +422,7 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   static_assert(SMEM_BYTES <= (KSP * PSP == 2 ? 160 : (KC == 32 ? 53 : 80)) * 1024, "workgroups per CU vs 160 KiB of LDS");
   static_assert(!SRC || NT >= 3, "the source copies retire at tap 2");
   static_assert(KC == 64 || (RT == 2 && BN == 128 && MODE != 2), "KC = 32 is built for the RT = 2, BN = 128 stride-1 tiles");
-  static_assert(SMEM_BYTES == conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP, PSP>(), "conv_lds_smem_bytes out of sync");
+  static_assert(SMEM_BYTES == conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP, PSP, TPS>(), "conv_lds_smem_bytes out of sync");
   const int grp = KSP == 2 ? (int)(threadIdx.x >> 8) : 0;  // K-split group of this wave
   const int pgr = PSP == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;  // pixel group of this wave
   unsigned char* w_tile = smem + grp * GROUP_BYTES;
@@ -470,16 +476,18 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   const unsigned short* wg = reinterpret_cast<const unsigned short*>(a.w);
   const int nchunks = a.Cin / KC / KSP;  // K chunks of this group
   const int cbase = grp * nchunks;        // first chunk of this group
-  const int nsteps = nchunks * NT;
+  const int nsteps = nchunks * NS;
   uint4 ireg[IPT];
   // weight slab of `step` -> ring slot: lane l of DMA block k lands at byte k*1024 + l*16,
   // i.e. row 8k + (l >> 3), 16-B slot l & 7, which must hold channel piece slot ^ swz(row)
+  constexpr int BPT = W1_BYTES / 1024;  // 1-KiB DMA blocks per tap
   auto issue_w = [&](int step, int slot) {
-    const int tap = step % NT, chunk = cbase + step / NT;
+    const int tap0 = (step % NS) * TPS, chunk = cbase + step / NS;
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       const int blk = i * NWV + dwave;
-      const int row = KC == 64 ? blk * 8 + (lane >> 3) : blk * 16 + (lane >> 2);
+      const int tap = tap0 + (TPS == 1 ? 0 : blk / BPT), rblk = TPS == 1 ? blk : blk % BPT;
+      const int row = KC == 64 ? rblk * 8 + (lane >> 3) : rblk * 16 + (lane >> 2);
       const int part = KC == 64 ? (lane & 7) ^ ((row >> 1) & 7) : (lane & 3) ^ ((row >> 2) & 3);
       const int co = min(n0 + row, a.Cout - 1);  // rows past Cout: any valid address (never stored)
       glds16(wg + ((size_t)tap * a.Cout + co) * a.Cin + chunk * KC + part * 8,
@@ -655,9 +663,10 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   };
 
   // one 1-KiB LDS-DMA block of the slab of `step` (block index i of this wave)
-  auto issue_w1 = [&](int tap, int chunk, int slot, int i) {
+  auto issue_w1 = [&](int st, int chunk, int slot, int i) {  // st = step inside the chunk
     const int blk = i * NWV + dwave;
-    const int row = KC == 64 ? blk * 8 + (lane >> 3) : blk * 16 + (lane >> 2);
+    const int tap = st * TPS + (TPS == 1 ? 0 : blk / BPT), rblk = TPS == 1 ? blk : blk % BPT;
+    const int row = KC == 64 ? rblk * 8 + (lane >> 3) : rblk * 16 + (lane >> 2);
     const int part = KC == 64 ? (lane & 7) ^ ((row >> 1) & 7) : (lane & 3) ^ ((row >> 2) & 3);
     const int co = min(n0 + row, a.Cout - 1);
 #if defined(LSS_CONV_DIAG_NOW)
@@ -712,17 +721,17 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   // are already in flight (32 fragment VGPRs in total), and one DMA block of the slab
   // two steps ahead is issued per k-step, so LDS latency and DMA issue hide behind
   // MFMAs.
-  constexpr int PF_TAP = NT >= 5 ? NT - 4 : 0;  // where the next patch's loads are issued
+  constexpr int PF_ST = NS >= 5 ? NS - 4 : 0;  // the step at which the next patch's loads are issued
   bf16x8 fa[2][RT], fb[2][2];  // [k-step parity][tile]
   auto read_a = [&](int buf, int tap, int s4) {
     const int toff = (tap / KW) * IROWB + (tap % KW) * POSB + s4 * 16;
 #pragma unroll
     for (int i = 0; i < RT; ++i) fa[buf][i] = *reinterpret_cast<const bf16x8*>(in_tile + aoff[i] + toff);
   };
-  auto read_b = [&](int buf, int slot, int s4) {
-    const unsigned char* wbuf = w_tile + slot * W_BYTES;
-    fb[buf][0] = *reinterpret_cast<const bf16x8*>(wbuf + boff[0][s4]);
-    fb[buf][1] = *reinterpret_cast<const bf16x8*>(wbuf + boff[1][s4]);
+  auto read_b = [&](int buf, int slot, int ks) {  // ks = k-step inside the step: tap ks / KS of the slab
+    const unsigned char* wbuf = w_tile + slot * W_BYTES + (ks / KS) * W1_BYTES;
+    fb[buf][0] = *reinterpret_cast<const bf16x8*>(wbuf + boff[0][ks % KS]);
+    fb[buf][1] = *reinterpret_cast<const bf16x8*>(wbuf + boff[1][ks % KS]);
   };
   int slot = 0;  // ring slot of the current step's slab
   for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -731,21 +740,21 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
     read_a(0, 0, 0);
     read_b(0, slot, 0);
 #pragma unroll
-    for (int tap = 0; tap < NT; ++tap) {
-      // slab two steps ahead: tap+2 of this chunk, or tap+2-NT of the next one
-      const int t2 = (tap + 2) % NT;
-      const int c2 = chunk + (tap + 2) / NT;
+    for (int st = 0; st < NS; ++st) {
+      // slab two steps ahead: step st+2 of this chunk, or st+2-NS of the next one
+      const int t2 = (st + 2) % NS;
+      const int c2 = chunk + (st + 2) / NS;
       const bool more = c2 < nchunks;
-      const bool prefetch = !FUSED && tap == PF_TAP && !last_chunk;
+      const bool prefetch = !FUSED && st == PF_ST && !last_chunk;
       const int slot2 = slot >= 1 ? slot - 1 : 2;  // (slot + 2) % 3
 #pragma unroll
-      for (int s4 = 0; s4 < KS; ++s4) {
-        const int cur = s4 & 1, nxt = cur ^ 1;
-        if (s4 < KS - 1) {
-          read_a(nxt, tap, s4 + 1);
-          read_b(nxt, slot, s4 + 1);
-        } else if (tap < NT - 1) {
-          read_a(nxt, tap + 1, 0);  // next tap's weights are only readable after the barrier
+      for (int ks = 0; ks < KS * TPS; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks < KS * TPS - 1) {
+          read_a(nxt, st * TPS + (ks + 1) / KS, (ks + 1) % KS);
+          read_b(nxt, slot, ks + 1);
+        } else if (st < NS - 1) {
+          read_a(nxt, (st + 1) * TPS, 0);  // next step's weights are only readable after the barrier
         }
         // keep the prefetch reads AHEAD of this k-step's MFMAs (hipcc's scheduler would
         // otherwise sink them next to their use and expose the LDS latency again)
@@ -763,16 +772,16 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
 #ifdef LSS_CONV_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
-        if (more && s4 < WPT) issue_w1(t2, c2, slot2, s4);
+        if (more && ks < WPT) issue_w1(t2, c2, slot2, ks);
       }
       // after this step's weight pieces, so that (like them) the copies have two steps to land: the
-      // counted waits of tap 0 and tap 1 leave them in flight, the wait of tap 2 retires them
-      if (SRC && tap == 0 && srcq) issue_src(chunk + 1);
+      // counted waits of step 0 and step 1 leave them in flight, the wait of step 2 retires them
+      if (SRC && st == 0 && srcq) issue_src(chunk + 1);
       if (prefetch) gather_in(chunk + 1, false);  // next patch -> registers
-      // PFB: the next chunk's source pixels landed with the wait of tap 2 (see below): blend them into registers now,
+      // PFB: the next chunk's source pixels landed with the wait of step 2 (see below): blend them into registers now,
       // under the MFMAs of the remaining taps
-      if (PFB && tap == PF_TAP && srcq) blend_to_regs();
-      if (tap == NT - 1 && !last_chunk) {
+      if (PFB && st == PF_ST && srcq) blend_to_regs();
+      if (st == NS - 1 && !last_chunk) {
         lds_barrier();  // every wave is done with this chunk's patch
         if (PFB && srcq) store_in();
         else if (FUSED) gather_fused(chunk + 1);
@@ -781,12 +790,12 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
       // W(step+1) must have landed in every wave's share before anyone reads it; only the
       // DMA (and patch loads) issued during THIS step may stay in flight
       if (prefetch) wait_vmcnt<WPT + IPT>();
-      else if (SRC && tap < 2 && srcq && more) wait_vmcnt<WPT + SRC_DMA>();
+      else if (SRC && st < 2 && srcq && more) wait_vmcnt<WPT + SRC_DMA>();
       else if (more) wait_vmcnt<WPT>();
       else wait_vmcnt<0>();
       lds_barrier();
       slot = slot == 2 ? 0 : slot + 1;
-      if (tap < NT - 1) read_b(0, slot, 0);
+      if (st < NS - 1) read_b(0, slot, 0);
     }
   }
 
@@ -1081,12 +1090,12 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
 }
 
 template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64, int KSP = 1, bool HEAD = false,
-          bool PFB = false, int PSP = 1>
+          bool PFB = false, int PSP = 1, int TPS = 1>
 __global__ __launch_bounds__(256 * KSP * PSP, KSP * PSP == 2 ? 1 : ((KC == 32 && !PFB) ? 3 : 2)) void conv_lds_kernel(
     ConvArgs a, int tilesX, int tilesY) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP, PSP>()];
-  conv_lds_tile<RT, BN, MODE, KH, KW, PAD, KC, KSP, HEAD, PFB, PSP>(a, tilesX, tilesY, blockIdx.x, gridDim.x,
-                                                                   blockIdx.y, 0, smem);
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP, PSP, TPS>()];
+  conv_lds_tile<RT, BN, MODE, KH, KW, PAD, KC, KSP, HEAD, PFB, PSP, TPS>(a, tilesX, tilesY, blockIdx.x, gridDim.x,
+                                                                        blockIdx.y, 0, smem);
 }
 
 // Mixed launch for grids that end in a partial round: the first `nfull` workgroups of every channel block are
@@ -1185,7 +1194,18 @@ void launch_conv_lds(const ConvArgs& a, hipStream_t st) {
   dim3 g(tilesX * tilesY * a.B, nblk);
   if (narrow) {
     if (rt == 2) hipLaunchKernelGGL((conv_lds_kernel<2, 64, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);
-    else hipLaunchKernelGGL((conv_lds_kernel<1, 64, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    else {
+      if constexpr (MODE == 2 && KH == 4) {
+        // the 7x7 / 2 stem: two taps per step (LSS_CONV_TPS=1 = one, for A/B)
+        static const bool tps2 = getenv("LSS_CONV_TPS") == nullptr || atoi(getenv("LSS_CONV_TPS")) != 1;
+        if (tps2) {
+          hipLaunchKernelGGL((conv_lds_kernel<1, 64, MODE, KH, KW, PAD, 64, 1, false, false, 1, 2>), g, dim3(256), 0, st, a,
+                             tilesX, tilesY);
+          return;
+        }
+      }
+      hipLaunchKernelGGL((conv_lds_kernel<1, 64, MODE, KH, KW, PAD>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    }
   } else {
     // Half-depth steps, three workgroups per CU.  Measured (same box, B = 4): the fused
     // upsample/concat convs gain (up1.conv0 100 -> 83 us, up2.1 141 -> 133 us: the third workgroup
