@@ -348,14 +348,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 // the third workgroup per CU: the blended pieces and their temporaries do not fit the 168-register budget - and that
 // turned out to cost more than the hidden blend returns (see conv_pfb_on): kept as a switchable variant.
 // LDS bytes of one workgroup of the tile body below (same formulas; the body static_asserts the match)
+#ifndef LSS_CONV_RING32
+#define LSS_CONV_RING32 4  // ring slots of the KC = 32 kernels (-DLSS_CONV_RING32=3: the round-1 depth, for A/B builds)
+#endif
 template <int RT, int BN, int MODE, int KH, int KW, int KC, int KSP, int PSP = 1, int TPS = 1>
 constexpr int conv_lds_smem_bytes() {
   constexpr int TH = (4 / (BN / 64)) * RT * 2, IW = 16 + KW - 1, IH = TH + KH - 1, POSB = KC * 2 + 16;
   constexpr int IROWB = (IW * POSB + 255) / 256 * 256, W_BYTES = TPS * BN * KC * 2, PPP = KC / 8;
   constexpr int OUT_BYTES = PSP * (TH / (KC == 32 ? 2 : 1)) * 16 * (BN + 4) * 4;
-  constexpr int GROUP_BYTES = (3 * W_BYTES + PSP * IH * IROWB + 1023) / 1024 * 1024;
-  constexpr int SRC_DMA = (MODE == 1 && KC == 32) ? (((IH - 1) / 2 + 3) * ((IW - 1) / 2 + 3) * PPP + 255) / 256 : 0;
-  return (KSP * GROUP_BYTES > OUT_BYTES ? KSP * GROUP_BYTES : OUT_BYTES) + PSP * SRC_DMA * 4096;
+  constexpr int GROUP_BYTES = ((KC == 32 ? LSS_CONV_RING32 : 3) * W_BYTES + PSP * IH * IROWB + 1023) / 1024 * 1024;
+  constexpr int SRC_PIECES = (MODE == 1 && KC == 32) ? (((IH - 1) / 2 + 3) * ((IW - 1) / 2 + 3) * PPP + 63) / 64 : 0;
+  return (KSP * GROUP_BYTES > OUT_BYTES ? KSP * GROUP_BYTES : OUT_BYTES) + PSP * SRC_PIECES * 1024;
 }
 
 // The tile body: one workgroup's output tile.  bid / nwg: index of the tile in its class and the size of the class
@@ -407,7 +410,11 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   // the epilogue stages the fp32 output tile in LDS: whole (KC = 64) or in two halves of TH/2 rows
   constexpr int EPH = KC == 32 ? 2 : 1;
   constexpr int OUT_BYTES = (TH / EPH) * 16 * OLD * 4;  // per pixel group
-  constexpr int GROUP_BYTES = (3 * W_BYTES + PSP * IN_BYTES + 1023) / 1024 * 1024;  // ring + patch(es) of one K-split group
+  // Weight ring: 3 slots = slabs two steps ahead of the MFMAs; the KC = 32 kernels (half-length steps, three
+  // workgroups per CU) keep 4 slots = three steps ahead: a timing build that re-read one L1-hot slab ran them 9-13 %
+  // faster while the KC = 64 kernel did not move, i.e. their shorter steps exposed the L2 round trip of the slab.
+  constexpr int NSL = KC == 32 ? LSS_CONV_RING32 : 3, LA = NSL - 1;
+  constexpr int GROUP_BYTES = (NSL * W_BYTES + PSP * IN_BYTES + 1023) / 1024 * 1024;  // ring + patch(es) of one K-split group
   // SRC (fused upsample, KC = 32): the low-res pixels a chunk's patch is interpolated from - at most
   // SRC_H x SRC_W source positions for scale factors >= 2 - are copied ONCE per chunk into LDS by
   // LDS-DMA while the previous chunk's taps run, and the 4-corner blend then reads LDS: 2 DMA
@@ -415,18 +422,19 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   // chunk-boundary phase (measured: that phase was 17 % of the fused convs).
   constexpr bool SRC = FUSED && KC == 32;
   constexpr int SRC_H = (IH - 1) / 2 + 3, SRC_W = (IW - 1) / 2 + 3;  // 7 x 11 for the 10 x 18 patch
-  constexpr int SRC_DMA = SRC ? (SRC_H * SRC_W * PPP + 255) / 256 : 0;  // DMA instructions per wave per chunk
-  constexpr int SRC_BYTES = SRC_DMA * 4096;
+  constexpr int SRC_PIECES = SRC ? (SRC_H * SRC_W * PPP + 63) / 64 : 0;  // 1-KiB DMA pieces per chunk (5)
+  constexpr int SRC_DMA = (SRC_PIECES + 3) / 4;  // DMA instructions per chunk of the wave that issues most (wave 0)
+  constexpr int SRC_BYTES = SRC_PIECES * 1024;
   constexpr int MAIN_BYTES = KSP * GROUP_BYTES > PSP * OUT_BYTES ? KSP * GROUP_BYTES : PSP * OUT_BYTES;
   constexpr int SMEM_BYTES = MAIN_BYTES + PSP * SRC_BYTES;
   static_assert(SMEM_BYTES <= (KSP * PSP == 2 ? 160 : (KC == 32 ? 53 : 80)) * 1024, "workgroups per CU vs 160 KiB of LDS");
-  static_assert(!SRC || NT >= 3, "the source copies retire at tap 2");
+  static_assert(!SRC || NS > LA, "the source copies retire at step LA");
   static_assert(KC == 64 || (RT == 2 && BN == 128 && MODE != 2), "KC = 32 is built for the RT = 2, BN = 128 stride-1 tiles");
   static_assert(SMEM_BYTES == conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP, PSP, TPS>(), "conv_lds_smem_bytes out of sync");
   const int grp = KSP == 2 ? (int)(threadIdx.x >> 8) : 0;  // K-split group of this wave
   const int pgr = PSP == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;  // pixel group of this wave
   unsigned char* w_tile = smem + grp * GROUP_BYTES;
-  unsigned char* in_tile = w_tile + 3 * W_BYTES + pgr * IN_BYTES;
+  unsigned char* in_tile = w_tile + NSL * W_BYTES + pgr * IN_BYTES;
   unsigned char* src_tile = smem + MAIN_BYTES + pgr * SRC_BYTES;  // SRC only
 
   const int tid = threadIdx.x & 255, lane = tid & 63;
@@ -606,7 +614,8 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
     const unsigned short* xp = reinterpret_cast<const unsigned short*>(a.x);
     const int cx = (cbase + chunk) * KC - a.C2;
 #pragma unroll
-    for (int i = 0; i < (SRC ? SRC_DMA : 0); ++i) glds16(xp + src_o[i] + cx, src_tile + (i * 4 + wave) * 1024);
+    for (int i = 0; i < (SRC ? SRC_DMA : 0); ++i)
+      if (i * 4 + wave < SRC_PIECES) glds16(xp + src_o[i] + cx, src_tile + (i * 4 + wave) * 1024);
   };
   // does `chunk` read the upsampled tensor through src_tile?
   auto src_chunk = [&](int chunk) { return use_src && chunk < nchunks && (cbase + chunk) * KC >= a.C2; };
@@ -704,7 +713,9 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   // prologue: W(0), W(1) on their way; patch of chunk 0
   if (src_chunk(0)) issue_src(0);
   issue_w(0, 0);
-  if (nsteps > 1) issue_w(1, 1);
+#pragma unroll
+  for (int q = 1; q < LA; ++q)
+    if (nsteps > q) issue_w(q, q);
   if (src_chunk(0)) {
     wait_vmcnt<0>();
     lds_barrier();  // the source pixels of chunk 0 are in LDS for every wave
@@ -741,12 +752,12 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
     read_b(0, slot, 0);
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
-      // slab two steps ahead: step st+2 of this chunk, or st+2-NS of the next one
-      const int t2 = (st + 2) % NS;
-      const int c2 = chunk + (st + 2) / NS;
+      // slab LA steps ahead: step st+LA of this chunk, or st+LA-NS of the next one
+      const int t2 = (st + LA) % NS;
+      const int c2 = chunk + (st + LA) / NS;
       const bool more = c2 < nchunks;
       const bool prefetch = !FUSED && st == PF_ST && !last_chunk;
-      const int slot2 = slot >= 1 ? slot - 1 : 2;  // (slot + 2) % 3
+      const int slot2 = slot >= 1 ? slot - 1 : NSL - 1;  // (slot + LA) % NSL
 #pragma unroll
       for (int ks = 0; ks < KS * TPS; ++ks) {
         const int cur = ks & 1, nxt = cur ^ 1;
@@ -789,12 +800,18 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
       }
       // W(step+1) must have landed in every wave's share before anyone reads it; only the
       // DMA (and patch loads) issued during THIS step may stay in flight
-      if (prefetch) wait_vmcnt<WPT + IPT>();
-      else if (SRC && st < 2 && srcq && more) wait_vmcnt<WPT + SRC_DMA>();
-      else if (more) wait_vmcnt<WPT>();
+      // (younger than W(step+1): the slabs of steps step+2 .. step+LA, and - in steps 0 .. LA-1 of a chunk - the source
+      // copies issued in its step 0: one per wave, two for the waves that carry the pieces past the fourth)
+      constexpr int WYOUNG = (LA - 1) * WPT;
+      if (prefetch) wait_vmcnt<WYOUNG + IPT>();
+      else if (SRC && st < LA && srcq && more) {
+        if (SRC_DMA == 2 && wave + 4 < SRC_PIECES) wait_vmcnt<WYOUNG + 2>();
+        else wait_vmcnt<WYOUNG + (SRC_DMA >= 1 ? 1 : 0)>();
+      }
+      else if (more) wait_vmcnt<WYOUNG>();
       else wait_vmcnt<0>();
       lds_barrier();
-      slot = slot == 2 ? 0 : slot + 1;
+      slot = slot == NSL - 1 ? 0 : slot + 1;
       if (st < NS - 1) read_b(0, slot, 0);
     }
   }
