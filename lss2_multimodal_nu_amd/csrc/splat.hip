@@ -309,14 +309,27 @@ __device__ __forceinline__ void region_accumulate_careful(const float* __restric
 template <int CPL, int LAYOUT>
 __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restrict__ feat,
                                                            const int2* __restrict__ entries, LssRegionPlan rp,
-                                                           int X, int Y, int Z, void* __restrict__ bev_) {
+                                                           int X, int Y, int Z, void* __restrict__ bev_,
+                                                           unsigned long long* stamps, int centre_out) {
   constexpr int C = 64 * CPL;
+  // LSS_L1_STAMPS diagnostic: s_memrealtime at entry / tile cleared / sums complete / stores issued; word 4 = points
+  unsigned long long* const stp = stamps ? stamps + (size_t)blockIdx.x * 8 : nullptr;
+  if (stp != nullptr && threadIdx.x == 0) stp[0] = __builtin_amdgcn_s_memrealtime();
   constexpr int RSIDE = LSS_REGION_SIDE;
   extern __shared__ __attribute__((aligned(16))) unsigned long long tile[];  // [64*Z][C] sums, then flag words
   __shared__ unsigned int wg_watch;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = blockIdx.x, b = r / rp.rps, rr = r - b * rp.rps;
-  const int rx = rr / rp.nRy, ry = rr - rx * rp.nRy;
+  // Block -> region: samples interleaved, and inside a sample the region rows - and the regions of a row - taken from
+  // the CENTRE of the grid outwards (centre, +1, -1, +2, ...).  The frustum points crowd around the ego vehicle, so the
+  // busiest regions (7-8 us of accumulation against a median of 2) are dispatched in the first round instead of
+  // starting 8 us into the launch as the last of 2.4 rounds: stamps put the launch's end at 18.8 us with the row-major
+  // order against ~12 us of work per slot.  A pure relabelling: every region is still visited exactly once.
+  const int nb = gridDim.x / rp.rps;  // samples
+  const int b = blockIdx.x % nb, kk = blockIdx.x / nb;
+  const int zi = kk / rp.nRy, zj = kk - zi * rp.nRy;
+  const int rx = centre_out ? (rp.nRx - 1) / 2 + ((zi & 1) ? (zi + 1) / 2 : -(zi / 2)) : zi;
+  const int ry = centre_out ? (rp.nRy - 1) / 2 + ((zj & 1) ? (zj + 1) / 2 : -(zj / 2)) : zj;
+  const int r = b * rp.rps + rx * rp.nRy + ry;
   const int ncell = RSIDE * RSIDE * Z;
   unsigned int* flags = reinterpret_cast<unsigned int*>(tile + (size_t)ncell * C);  // [ncell*C/32]
   const int n = rp.region_count[r];
@@ -349,6 +362,7 @@ __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restri
     }
     for (int i = tid; i < zero_n; i += 256) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
+    if (stp != nullptr && tid == 0) stp[1] = __builtin_amdgcn_s_memrealtime();
     const __amdgpu_buffer_rsrc_t frs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feat), 0, 0x7fffffff, 0x00020000);
     unsigned long long* const my_col = tile + lane;  // lane = channel
@@ -392,6 +406,7 @@ __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restri
     }
     if (watch >= 0x7f800000u) atomicOr(&wg_watch, 1u);
     __syncthreads();
+    if (stp != nullptr && tid == 0) stp[2] = __builtin_amdgcn_s_memrealtime();
     if (wg_watch != 0) {  // rare: a non-finite product - redo the region element by element, with flags
       __syncthreads();
       for (int i = tid; i < zero_n; i += 256) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
@@ -451,6 +466,13 @@ __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restri
         ov.z = lss_pack_bf2(v[4], v[5]); ov.w = lss_pack_bf2(v[6], v[7]);
         *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(bev_) + o) = ov;
       }
+    }
+  }
+  if (stp != nullptr) {
+    __syncthreads();
+    if (tid == 0) {
+      stp[3] = __builtin_amdgcn_s_memrealtime();
+      stp[4] = (unsigned long long)n;
     }
   }
 }
@@ -635,8 +657,12 @@ static int region_splat_launch(const float* feat, const int32_t* entries, const 
   const size_t lds = (size_t)64 * Z * C * 8 + (size_t)64 * Z * C / 8;
   dim3 grid(B * rp.rps);
   const int2* en = reinterpret_cast<const int2*>(entries);
+  // diagnostic runs: the splat's stamps follow the 16384 slots of the K2 || K3 launch in the same buffer
+  unsigned long long* stamps = getenv("LSS_L1_STAMPS")
+      ? reinterpret_cast<unsigned long long*>(strtoull(getenv("LSS_L1_STAMPS"), nullptr, 16)) + (size_t)16384 * 8 : nullptr;
+  static const int centre_out = getenv("LSS_SPLAT_ORDER") == nullptr || atoi(getenv("LSS_SPLAT_ORDER")) != 0;
 #define LSS_RS(CPL, LAY) \
-  hipLaunchKernelGGL((region_splat_kernel<CPL, LAY>), grid, dim3(256), lds, st, feat, en, rp, X, Y, Z, bev)
+  hipLaunchKernelGGL((region_splat_kernel<CPL, LAY>), grid, dim3(256), lds, st, feat, en, rp, X, Y, Z, bev, stamps, centre_out)
   if (C == 64) {
     if (layout == LSS_BEV_NCHW_F32) LSS_RS(1, LSS_BEV_NCHW_F32);
     else if (layout == LSS_BEV_NHWC_F32) LSS_RS(1, LSS_BEV_NHWC_F32);

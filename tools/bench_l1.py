@@ -41,7 +41,7 @@ def main():
         with torch.no_grad():
             for _ in range(5):
                 step()
-            buf = torch.zeros(16384 * 8, dtype=torch.int64, device="cuda")
+            buf = torch.zeros(2 * 16384 * 8, dtype=torch.int64, device="cuda")
             os.environ["LSS_L1_STAMPS"] = "%x" % buf.data_ptr()
             for _ in range(3):
                 buf.zero_()
@@ -49,7 +49,10 @@ def main():
                 step()
                 torch.cuda.synchronize()
             del os.environ["LSS_L1_STAMPS"]
-        t = buf.view(-1, 8).cpu().numpy().astype(np.float64) * 0.01  # us
+        raw = buf.view(-1, 8).cpu().numpy()
+        sp = raw[16384:]
+        sp = sp[sp[:, 0] != 0]
+        t = raw[:16384].astype(np.float64) * 0.01  # us
         live = t[:, 0] != 0
         t0 = t[live, 0].min()
         ids = np.arange(len(t))
@@ -65,6 +68,22 @@ def main():
                 print("   epilogue             %s" % f(q[:, 3] - q[:, 2]))
             print("   whole workgroup      %s" % f(q[:, 3] - q[:, 0]))
             print("   end after launch     %s" % f(q[:, 3] - t0))
+        # region splat: one workgroup per region
+        q = sp[:, :4].astype(np.float64) * 0.01
+        npts = sp[:, 4]
+        s0 = q[:, 0].min()
+        print("region splat     %5d workgroups, %d points, busiest region %d points, %d empty regions" % (
+            len(q), npts.sum(), npts.max(), (npts == 0).sum()))
+        print("   start after launch   %s" % f(q[:, 0] - s0))
+        ne = npts > 0
+        print("   clear tile (n > 0)   %s" % f(q[ne, 1] - q[ne, 0]))
+        print("   accumulate (n > 0)   %s" % f(q[ne, 2] - q[ne, 1]))
+        print("   convert + store      %s" % f(np.where(ne, q[:, 3] - q[:, 2], q[:, 3] - q[:, 0])))
+        print("   whole workgroup      %s" % f(q[:, 3] - q[:, 0]))
+        print("   end after launch     %s" % f(q[:, 3] - s0))
+        order = np.argsort(-npts)[:5]
+        print("   five busiest regions: points %s, accumulate us %s, start us %s" % (
+            npts[order].tolist(), np.round(q[order, 2] - q[order, 1], 2).tolist(), np.round(q[order, 0] - s0, 2).tolist()))
         return
     for mode in args.modes.split(","):
         os.environ.pop("LSS_SPLAT_LEGACY", None)
