@@ -86,6 +86,8 @@ CASES = [
                               dbound=[2.0, 9.0, 1.0]), (64, 80), True),          # 50 x 24, C = 128
     (1, 6, 41, 8, 22, 64, dict(xbound=[-50.0, 50.0, 2.0], ybound=[-50.0, 50.0, 2.0], zbound=[-10.0, 10.0, 20.0],
                                dbound=[4.0, 45.0, 1.0]), (128, 352), False),     # coarse 50 x 50: ~70 points per cell
+    (1, 2, 41, 8, 22, 64, dict(xbound=[-50.0, 50.0, 100.0], ybound=[-50.0, 50.0, 100.0], zbound=[-10.0, 10.0, 20.0],
+                               dbound=[4.0, 45.0, 1.0]), (128, 352), False),     # ONE cell: >10 000 points collide in it
 ]
 
 

@@ -67,7 +67,7 @@ def main():
                 "SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs)\n")
         w("conv_pmc_sq.txt", head + run_tool("pmc_sq_summary.py", sq, sqkt))
     for tag, out in (("bk_conv.txt", "conv_microbench.txt"), ("bk_stamps.txt", "conv_phase_stamps.txt"),
-                     ("bk_l1.txt", "l1_microbench.txt")):
+                     ("bk_l1.txt", "l1_microbench.txt"), ("l1_stamps.txt", "l1_stamps.txt")):
         p = os.path.join(src, tag)
         if os.path.exists(p):
             w(out, "".join(ln for ln in open(p) if "amdgpu.ids" not in ln))

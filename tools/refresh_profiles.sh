@@ -8,9 +8,10 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 ROUND=${ROUND:-r02}
 OUT=$R/gpurun_out/prof_$ROUND
 rm -rf "$OUT" && mkdir -p "$OUT"
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-train"
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-train --no-two-streams"  # profiled runs: the single-stream loop only
 cd $R
 python bench.py --steps 100 --warmup 10 > $OUT/bench_line.json 2> $OUT/bench_line.err
+echo "bench line done" 
 python bench.py --workload hires --steps 50 --warmup 10 --no-train --no-cpu-baseline > $OUT/bench_hires.json 2>/dev/null
 python bench.py --precision fp32 --steps 20 --warmup 5 --no-train --no-cpu-baseline > $OUT/bench_fp32.json 2>/dev/null
 python bench.py --workload config1 --steps 100 --warmup 10 --no-train > $OUT/bench_config1.json 2>/dev/null
@@ -18,6 +19,7 @@ LSS_BENCH_REHEARSE=1 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-bas
 python tools/bench_kernels.py --only conv > $OUT/bk_conv.txt 2>&1
 python tools/bench_kernels.py --only stamps > $OUT/bk_stamps.txt 2>&1
 python tools/bench_kernels.py --only l1 > $OUT/bk_l1.txt 2>&1
+python tools/bench_l1.py --stamps > $OUT/l1_stamps.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $R/bench.py $ARGS > $OUT/kt.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python $R/bench.py $ARGS > $OUT/fetch.log 2>&1
@@ -25,10 +27,10 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- p
 # the same WRITE_SIZE pass with the spill-free (2 workgroups / CU) build of the fused upsample convs: separates scratch
 # write-backs from the kernels' own stores ("WRITE_SIZE above the algorithmic bytes")
 LSS_CONV_PFB=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write_nospill -- python $R/bench.py $ARGS > $OUT/write_nospill.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/sq -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-train > $OUT/sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/sq -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-train --no-two-streams > $OUT/sq.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_hires -- python $R/bench.py --workload hires $ARGS > $OUT/kt_hires.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_fp32 -- python $R/bench.py --precision fp32 --steps 10 --warmup 3 --no-cpu-baseline --no-train > $OUT/kt_fp32.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_train -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --train-steps 10 > $OUT/kt_train.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_fp32 -- python $R/bench.py --precision fp32 --steps 10 --warmup 3 --no-cpu-baseline --no-train --no-two-streams > $OUT/kt_fp32.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_train -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-two-streams --train-steps 10 > $OUT/kt_train.log 2>&1
 cd $R
 find $OUT -name "*.csv" | wc -l
 tail -c 600 $OUT/bench_line.json
