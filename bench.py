@@ -328,23 +328,45 @@ def main():
         out["levels"]["two_batches_in_flight_note"] = ("same K steps alternated over 2 HIP streams / 2 model instances "
                                                        "(informational; `value` is the single-stream loop)")
 
-    # ---- training step (fwd + bwd + Adam, RCCL all-reduce of one flat gradient bucket) ----
-    if not args.no_train and args.workload == "config2":
-        # An extra, informational leg: a failure in it (every rank sees the same exception class) must not cost the
-        # main metric's line, so it is reported instead of raised.
-        try:
-            out["train"] = train_leg(args, model, feats, calib, dev, dist, world, B)
-        except Exception as e:  # noqa: BLE001
-            out["train"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-
     # ---- CPU baseline: the oracle (op-for-op torch port of the reference) on this host ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("config2", "config1"):
         out["cpu_baseline"] = cpu_baseline(model, feats, calib, B)
 
+    # ---- training step (fwd + bwd + Adam, RCCL all-reduce of one flat gradient bucket) ----
+    if not args.no_train and args.workload == "config2":
+        # An extra, informational leg: a failure in it (every rank sees the same exception class) must not cost the
+        # main metric's line, so it is reported instead of raised.
+        # ... and a HANG in it (a collective some rank never joins) must not either: every rank arms a watchdog that
+        # prints the line without the leg (rank 0) and leaves, so the launcher always sees N clean exits.
+        wd = _arm_watchdog(float(os.environ.get("LSS_BENCH_TRAIN_TIMEOUT", "300")),
+                           dict(out, train={"error": "watchdog: the train leg did not finish in time"}), rank)
+        try:
+            out["train"] = train_leg(args, model, feats, calib, dev, dist, world, B)
+        except Exception as e:  # noqa: BLE001
+            out["train"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        wd.cancel()
+
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
+        wd = _arm_watchdog(60.0, None, -1)  # the line is out: a teardown that hangs ends in a plain exit
         dist.destroy_process_group()
+        wd.cancel()
+
+
+def _arm_watchdog(seconds, line, rank):
+    """After `seconds`: rank 0 prints `line` (the JSON object of everything measured so far) and every rank exits 0."""
+    import threading
+
+    def fire():
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def train_leg(args, model, feats, calib, dev, dist, world, B):
