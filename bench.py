@@ -232,29 +232,7 @@ def main():
         barrier()
         dt_l1 = time.perf_counter() - t1
 
-        # ---- informational: two batches in flight (two HIP streams, one model instance each) ------
-        # The single-stream number above stays `value`.  This leg shows how much of the step is
-        # latency (the launch-bound BevEncode layers and the lift-splat level leave CUs idle that a
-        # second, independent batch can use) - what a serving loop that double-buffers batches gets.
-        dt_2s = 0.0
-        if args.two_streams:
-            model_b = L.compile_model_lss(B, grid, aug, 4, precision=args.precision).to(dev).eval()
-            model_b.load_state_dict(model.state_dict())
-            models = (model, model_b)
-            streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-            torch.cuda.synchronize()
-            for i in range(6):
-                with torch.cuda.stream(streams[i & 1]):
-                    models[i & 1](feats, *calib)
-            barrier()
-            t2 = time.perf_counter()
-            for i in range(args.steps):
-                with torch.cuda.stream(streams[i & 1]):
-                    models[i & 1](feats, *calib)
-            barrier()
-            dt_2s = time.perf_counter() - t2
-
-    tmax = torch.tensor([dt, dt_l1, dt_2s], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt, dt_l1], dtype=torch.float64, device=dev)
     per_rank = [args.steps * B / dt]
     comm = {"backend": "none", "ranks": 1}
     if dist is not None:
@@ -268,7 +246,7 @@ def main():
         comm = {"backend": dist.get_backend(), "ranks": int(ones[0]),
                 "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if not rehearse else None,
                 "devices": "all ranks on cuda:0 (LSS_BENCH_REHEARSE)" if rehearse else "one GPU per rank (LOCAL_RANK)"}
-    dt, dt_l1, dt_2s = float(tmax[0]), float(tmax[1]), float(tmax[2])
+    dt, dt_l1 = float(tmax[0]), float(tmax[1])
     frames = args.steps * B * world
     fps = frames / dt
 
@@ -323,15 +301,6 @@ def main():
                    "L1_frac_of_hbm_peak": l1_bytes_step * args.steps / dt_l1 / 1e9 / HBM_PEAK_GBS},
     }
 
-    if dt_2s > 0:
-        out["levels"]["two_batches_in_flight_fps"] = frames / dt_2s
-        out["levels"]["two_batches_in_flight_note"] = ("same K steps alternated over 2 HIP streams / 2 model instances "
-                                                       "(informational; `value` is the single-stream loop)")
-
-    # ---- CPU baseline: the oracle (op-for-op torch port of the reference) on this host ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("config2", "config1"):
-        out["cpu_baseline"] = cpu_baseline(model, feats, calib, B)
-
     # ---- training step (fwd + bwd + Adam, RCCL all-reduce of one flat gradient bucket) ----
     if not args.no_train and args.workload == "config2":
         # An extra, informational leg: a failure in it (every rank sees the same exception class) must not cost the
@@ -345,6 +314,41 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["train"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         wd.cancel()
+
+    # ---- informational: two batches in flight (two HIP streams, one model instance each) ------
+    # The single-stream number above stays `value`.  This leg shows how much of the step is
+    # latency (the launch-bound BevEncode layers and the lift-splat level leave CUs idle that a
+    # second, independent batch can use) - what a serving loop that double-buffers batches gets.
+    dt_2s = 0.0
+    if args.two_streams:
+        with torch.no_grad():
+            model_b = L.compile_model_lss(B, grid, aug, 4, precision=args.precision).to(dev).eval()
+            model_b.load_state_dict(model.state_dict())
+            models = (model, model_b)
+            streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            torch.cuda.synchronize()
+            for i in range(6):
+                with torch.cuda.stream(streams[i & 1]):
+                    models[i & 1](feats, *calib)
+            barrier()
+            t2 = time.perf_counter()
+            for i in range(args.steps):
+                with torch.cuda.stream(streams[i & 1]):
+                    models[i & 1](feats, *calib)
+            barrier()
+            dt_2s = time.perf_counter() - t2
+    if dt_2s > 0:
+        if dist is not None:
+            t2s = torch.tensor([dt_2s], dtype=torch.float64, device=dev)
+            dist.all_reduce(t2s, op=dist.ReduceOp.MAX)
+            dt_2s = float(t2s[0])
+        out["levels"]["two_batches_in_flight_fps"] = frames / dt_2s
+        out["levels"]["two_batches_in_flight_note"] = ("same K steps alternated over 2 HIP streams / 2 model instances "
+                                                       "(informational; `value` is the single-stream loop)")
+
+    # ---- CPU baseline: the oracle (op-for-op torch port of the reference) on this host ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("config2", "config1"):
+        out["cpu_baseline"] = cpu_baseline(model, feats, calib, B)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -449,6 +453,7 @@ def cpu_baseline(model, feats, calib, B):
     from oracle import bev_oracle as bo
     from oracle import lss_oracle as lo
     ncores = host_cores()
+    threads_before = torch.get_num_threads()
     torch.set_num_threads(ncores)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     bsd = {k[len("bevencode."):]: v for k, v in sd.items() if k.startswith("bevencode.")}
@@ -467,6 +472,7 @@ def cpu_baseline(model, feats, calib, B):
             bo.bev_encode(grid, bsd); t2 = time.perf_counter()
             t_l1.append(t1 - t0); t_l2.append(t2 - t0)
     t_l1.sort(); t_l2.sort()
+    torch.set_num_threads(threads_before)
     return {"value": B / t_l2[1], "unit": "frames/s", "cores": ncores, "kind": "port",
             "sample": "3 passes of batch %d (median), fp32, full hot path; L1 (lift-splat only) = %.1f frames/s"
                       % (B, B / t_l1[1]),

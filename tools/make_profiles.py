@@ -16,8 +16,10 @@ sys.path.insert(0, HERE)
 
 
 def find(d, pat):
-    g = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
-    return g[0] if g else None
+    # newest match: gpurun MERGES a call's files into gpurun_out/, so an earlier collection's files (other process
+    # ids in their names) may still lie next to the current ones
+    g = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True), key=os.path.getmtime)
+    return g[-1] if g else None
 
 
 def run_tool(script, *args):
