@@ -561,16 +561,22 @@ static int depthnet_voxels_impl(const float* frustum, const float* inv_post_rots
   }
   // the row-split K2 (region pipeline, the shapes of the LSS depthnet: D <= 48, C <= 64, Cin a multiple of 128)
   static const bool rows_off = getenv("LSS_K2_ROWS") != nullptr && atoi(getenv("LSS_K2_ROWS")) == 0;
-  if (plan != nullptr && !rows_off && (D + 15) / 16 == 3 && (C + 15) / 16 == 4 && Cin % 128 == 0 &&
+  const int nd16 = (D + 15) / 16;
+  if (plan != nullptr && !rows_off && (nd16 == 3 || nd16 == 4) && (C + 15) / 16 == 4 && Cin % 128 == 0 &&
       ((size_t)D * Cin * sizeof(float)) % 16 == 0) {
     const long long nb = nblk + a.n2;
     if (nb >= (1LL << 31)) return LSS_E_SHAPE;
     size_t lb = (size_t)5 * 4 * 16 * lss_depthnet::LDS_LD * sizeof(float);
     if ((size_t)plan->rps * sizeof(int) > lb) lb = (size_t)plan->rps * sizeof(int);
-    if (calib_host != nullptr)
-      hipLaunchKernelGGL((depthnet_rows_and_voxels_kernel<3, 4, true>), dim3((unsigned)nb), dim3(256), lb, st, a, cal, 2 * a.n2);
-    else
-      hipLaunchKernelGGL((depthnet_rows_and_voxels_kernel<3, 4, false>), dim3((unsigned)nb), dim3(256), lb, st, a, cal, 2 * a.n2);
+#define LSS_ROWS(ND, HC)                                                                                          \
+    hipLaunchKernelGGL((depthnet_rows_and_voxels_kernel<ND, 4, HC>), dim3((unsigned)nb), dim3(256), lb, st, a, cal, \
+                       2 * a.n2)
+    if (nd16 == 3) {  // D <= 48: the 41 bins of the 352 x 128 configurations
+      if (calib_host != nullptr) LSS_ROWS(3, true); else LSS_ROWS(3, false);
+    } else {          // D <= 64: the 60 bins of the 704 x 256 configuration
+      if (calib_host != nullptr) LSS_ROWS(4, true); else LSS_ROWS(4, false);
+    }
+#undef LSS_ROWS
     return lss_launch_status();
   }
 #define LSS_F_CASE(n)                                                                                          \

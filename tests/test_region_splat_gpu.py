@@ -86,14 +86,15 @@ CASES = [
                               dbound=[2.0, 9.0, 1.0]), (64, 80), True),          # 50 x 24, C = 128
     (1, 6, 41, 8, 22, 64, dict(xbound=[-50.0, 50.0, 2.0], ybound=[-50.0, 50.0, 2.0], zbound=[-10.0, 10.0, 20.0],
                                dbound=[4.0, 45.0, 1.0]), (128, 352), False),     # coarse 50 x 50: ~70 points per cell
-    (1, 2, 41, 8, 22, 64, dict(xbound=[-50.0, 50.0, 100.0], ybound=[-50.0, 50.0, 100.0], zbound=[-10.0, 10.0, 20.0],
-                               dbound=[4.0, 45.0, 1.0]), (128, 352), False),     # ONE cell: >10 000 points collide in it
+    (1, 2, 41, 8, 22, 64, dict(xbound=[-50.0, 50.0, 25.0], ybound=[-50.0, 50.0, 25.0], zbound=[-10.0, 10.0, 20.0],
+                               dbound=[4.0, 45.0, 1.0]), (128, 352), False),     # 4 x 4 cells, one region: thousands of
+                                                                                 # points collide in each central cell
 ]
 
 
 @pytest.mark.parametrize("case", range(len(CASES)))
 @pytest.mark.parametrize("layout", [0, 1, 2])
-def test_region_pipeline_vs_fp64_and_voxel_list_pipeline(ops, monkeypatch, case, layout):
+def test_region_pipeline_vs_fp64_and_voxel_list_pipeline(ops, monkeypatch, report, case, layout):
     B, N, D, fH, fW, C, grid, fd, rc = CASES[case]
     pr = problem(B, N, D, fH, fW, C, grid, fd, seed=case, randn_calib=rc)
     bev, depth, feat, ws = run(ops, pr, layout, False, monkeypatch)
@@ -112,10 +113,20 @@ def test_region_pipeline_vs_fp64_and_voxel_list_pipeline(ops, monkeypatch, case,
     assert np.array_equal(ws.voxel.cpu().numpy().reshape(vid.shape), vid)
     # region pipeline: fixed-point sums, exact to one fp32 rounding; voxel-list pipeline: fp32 sums of up to ~70 terms
     # per cell, a few 1e-7 of max|ref|; bf16 output: one more rounding of the sum
-    tol = 2e-6 if layout != 2 else 4e-3
-    for got in (bev, bev_l):
+    # (case 4: thousands of signed fp32 terms per channel in the voxel-list pipeline's chunked sum - its error grows
+    # with sum |term|, ~1e-6 of max|ref| and different from run to run; the region pipeline's fixed-point sum keeps
+    # its single rounding whatever the count)
+    # Region pipeline, fp32 layouts: 2e-7 - only an exact sum rounded once gets there (measured 3e-8 ... 5e-8), so
+    # this also proves that the region pipeline, not a fallback, produced `bev`.
+    tol_list = 2e-6 if layout != 2 else 4e-3
+    tol = 2e-7 if layout != 2 else 4e-3
+    if case == 4:
+        tol_list = max(tol_list, 3e-4)
+    for name, got, tl in (("region", bev, tol), ("voxel-list", bev_l, tol_list)):
         g = got.float().cpu().numpy().astype(np.float64)
-        assert np.abs(g - ref).max() <= tol * max(np.abs(ref).max(), 1e-30)
+        err = report("region_splat case %d layout %d %s: max err / max|ref|" % (case, layout, name),
+                     np.abs(g - ref).max() / max(np.abs(ref).max(), 1e-30))
+        assert err <= tl, name
         assert np.array_equal(g != 0, ref != 0) or layout == 2  # empty cells are exact zeros
     # workspace contract: the zero-between-calls words are zero again
     assert int(ws.vox_count.abs().sum()) == 0 and int(ws.cursor.abs().sum()) == 0
