@@ -222,6 +222,17 @@ def main():
         dt = time.perf_counter() - t0
         ops.set_timer(None)
         spans = timer.totals_ms()
+        # ---- the dominant kernel on its own (outside the timed region: a bracket costs ~10 us of idle) ----
+        # Same steps again with BevEncode's recorded launch list replayed in two calls, so that its LAST launch - up2:
+        # x2 upsample + 3x3 conv 256 -> 128 + BN + ReLU + fused 1x1 head, 38 % of the step's FLOPs - gets a HIP-event
+        # bracket of its own; profiles/r02_bench_kernel_summary.txt holds the same kernel's rocprofv3 average.
+        timer_k = ops.KernelTimer(last_conv=True)
+        ops.set_timer(timer_k)
+        for _ in range(args.steps):
+            step()
+        barrier()
+        ops.set_timer(None)
+        n_dom, ms_dom = timer_k.totals_ms().get("conv_plan_last", (0, 0.0))
         # ---- L1 only (lift-splat level), same protocol ---------------------------------
         for _ in range(3):
             step_l1()
@@ -263,6 +274,17 @@ def main():
     spl_gbs = splat_bytes_step * args.steps / (ms_spl * 1e-3) / 1e9 if ms_spl else 0.0
 
     conv_traffic, splat_traffic = pmc_traffic("conv_"), pmc_traffic("region_splat_kernel")
+    # the dominant kernel by itself: algorithmic FLOPs of ONE launch / its own average duration
+    dom_flops = 2.0 * B * X * Y * 128 * (256 * 9 + 4)   # 3x3 256 -> 128 on the upsampled grid + the 1x1 head (4 classes)
+    dom_us = ms_dom * 1e3 / n_dom if n_dom else 0.0
+    dom_tf = dom_flops / (dom_us * 1e-6) / 1e12 if dom_us else 0.0
+    dom_traffic = pmc_traffic("conv_lds_kernel<2, 128, 1, 3, 3, 1, 32, 1, true")
+    dominant = {"kernel": "conv_lds_kernel<2,128,1,3,3,1,32,1,HEAD> = BevEncode.up2: x2 bilinear upsample (fused gather) + 3x3 "
+                          "conv 256->128 + BN + ReLU + 1x1 head, one launch; own HIP-event bracket in a separate pass of the "
+                          "same K steps (outside the timed region)",
+                "bound": "mfma", "flops_per_launch": dom_flops, "avg_us": dom_us, "launches": n_dom, "achieved": dom_tf,
+                "peak": peak_tf, "unit": "TFLOP/s", "frac": dom_tf / peak_tf if peak_tf else 0.0,
+                "traffic": dom_traffic[0], "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": dom_traffic[1]}
     out = {
         "metric": "BEV frames/sec (6-cam 352x128 -> 200x200x64), full hot path: CamEncode lift + splat + BevEncode",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -285,7 +307,8 @@ def main():
                      "bound": "mfma", "achieved": conv_tf, "peak": peak_tf, "unit": "TFLOP/s",
                      "frac": conv_tf / peak_tf, "traffic": conv_traffic[0], "traffic_unit": "HBM bytes per launch (PMC)",
                      "traffic_source": conv_traffic[1], "launches": n_conv * 16,
-                     "avg_us": ms_conv * 1e3 / max(n_conv * 16, 1), "flops_per_step": conv_flops_step},
+                     "avg_us": ms_conv * 1e3 / max(n_conv * 16, 1), "flops_per_step": conv_flops_step,
+                     "dominant_kernel": dominant},
         "roofline_l1": {"kernel": "lift-splat level = depthnet_rows_and_voxels (K2 || K3) + region_fill + region_splat "
                                   "(3 launches, one HIP-event bracket); `traffic` is region_splat_kernel's own",
                         "bound": "hbm", "achieved": spl_gbs, "peak": HBM_PEAK_GBS,

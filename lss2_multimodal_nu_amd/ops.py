@@ -25,11 +25,15 @@ class KernelTimer:
     the roofline numbers).  Events are recorded on torch's current stream - the
     stream the kernels are enqueued on."""
 
-    def __init__(self, fine=False):
+    def __init__(self, fine=False, last_conv=False):
         # fine=True brackets every native launch (each bracket costs ~5-10 us of GPU idle
-        # time: diagnostics only); fine=False only the regions opened with `region()`
+        # time: diagnostics only); fine=False only the regions opened with `region()`.
+        # last_conv=True: a recorded conv plan is replayed in two native calls and its LAST launch
+        # (BevEncode: up2 3x3 + BN + ReLU + fused 1x1 head, the dominant kernel) gets a bracket of
+        # its own, tag "conv_plan_last" - bench.py's separate per-kernel roofline pass.
         self.spans = {}
         self.fine = fine
+        self.last_conv = last_conv
 
     def bracket(self, tag):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -117,6 +121,13 @@ class ConvPlan:
             setattr(self.arr[i], name, pin)
         for i, name in self.out_slots:
             setattr(self.arr[i], name, pout)
+        if _timer is not None and _timer.last_conv and self.n > 1:
+            import ctypes
+            N.check(N.lib().lss_conv2d_sequence(self.arr, self.n - 1, N.stream()), "lss_conv2d_sequence")
+            last = ctypes.byref(self.arr, (self.n - 1) * ctypes.sizeof(self.arr[0]))  # &arr[n - 1]
+            with _timed("conv_plan_last", coarse=True):
+                N.check(N.lib().lss_conv2d_sequence(last, 1, N.stream()), "lss_conv2d_sequence")
+            return
         N.check(N.lib().lss_conv2d_sequence(self.arr, self.n, N.stream()), "lss_conv2d_sequence")
 
 
