@@ -435,8 +435,10 @@ int lss_conv2d_sequence(const lss_conv_launch_t* launches, int n, void* stream);
 /* The whole lift-splat level in one call (same arguments as the individual entries).
  * With math = LSS_DT_F32 (and 64*Z <= 256, B*X*Y*Z large enough to hold the region words below) it runs the
  * REGION-BUCKETED pipeline, three launches:
- *   1. K2 || K3: depthnet + softmax  ||  points -> voxel ids, each workgroup counting its 256 points per 8 x 8-cell
- *      region in LDS and issuing one global atomic per non-empty region (no per-point atomics);
+ *   1. K2 || K3: depthnet + softmax (for D <= 64, C <= 64 two workgroups per 16-pixel tile: the depth rows + softmax
+ *      and the context rows; the K sum is associated in 32-deep blocks, so depth / feat may differ from
+ *      lss_depthnet_softmax_fwd's in the last ulp)  ||  points -> voxel ids, each workgroup counting its 256 points per
+ *      8 x 8-cell region in LDS and issuing one global atomic per non-empty region (no per-point atomics);
  *   2. fill: per-workgroup LDS ranks + one global atomic per (workgroup, region) -> entries grouped by region;
  *   3. region splat: one workgroup per region, int64 fixed-point sums in an LDS tile (associative, so the
  *      result is bit-reproducible whatever order the atomics produced), coalesced BEV stores incl. zeros.
