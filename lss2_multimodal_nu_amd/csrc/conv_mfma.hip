@@ -429,6 +429,9 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   constexpr int SMEM_BYTES = MAIN_BYTES + PSP * SRC_BYTES;
   static_assert(SMEM_BYTES <= (KSP * PSP == 2 ? 160 : (KC == 32 ? 53 : 80)) * 1024, "workgroups per CU vs 160 KiB of LDS");
   static_assert(!SRC || NS > LA, "the source copies retire at step LA");
+  // (A 16-row tile for the fused x2 conv - RT = 4: a wave owns 4 x 2 MFMA tiles, half the DMA pieces and 3/4 of the LDS
+  // fragment reads per MFMA, epilogue in four passes - was built and measured in round 2: 256 registers with spills, two
+  // workgroups per CU instead of three, up2 + head 123.5 -> 132.0 us on the same box.  Not kept.)
   static_assert(KC == 64 || (RT == 2 && BN == 128 && MODE != 2), "KC = 32 is built for the RT = 2, BN = 128 stride-1 tiles");
   static_assert(SMEM_BYTES == conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP, PSP, TPS>(), "conv_lds_smem_bytes out of sync");
   const int grp = KSP == 2 ? (int)(threadIdx.x >> 8) : 0;  // K-split group of this wave
