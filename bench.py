@@ -215,23 +215,41 @@ def main():
         # milliseconds under load to reach the clock it then sustains; measured on MI355X, the same kernels run 4 %
         # slower in a 20-step (10 ms) run that starts from an idle device than in a 400-step one (conv group 458 vs
         # 435 us).  The W warm-up steps and the K timed steps below are untouched.
+        # The driver's nominal protocol first, from a device that has only seen the W warm-up steps: reported as
+        # levels.cold_start_fps (both numbers in the line).
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        tc = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt_cold = time.perf_counter() - tc
         t_spin = time.perf_counter() + args.spinup_ms * 1e-3
         while time.perf_counter() < t_spin:
             step()
         for _ in range(args.warmup):
             step()
-        # ---- timed region: EXACTLY args.steps steps --------------------------------
-        timer = ops.KernelTimer()
-        ops.set_timer(timer)
+        # ---- timed region: EXACTLY args.steps steps, NO instrumentation inside ------------------
+        # (round 2 kept two HIP-event brackets per step in here: the trace showed 10-17 us of idle at each, ~4 % of
+        # the step - it was timing the probe.  The roofline brackets now run in their own pass below.)
+        ops.set_timer(None)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         barrier()
         dt = time.perf_counter() - t0
+        # ---- roofline pass: the same K steps with ONE HIP-event bracket around the lift-splat level and one around
+        # the BevEncode launch group (outside the timed region) -------------------------------------------------
+        timer = ops.KernelTimer()
+        ops.set_timer(timer)
+        for _ in range(args.steps):
+            step()
+        barrier()
         ops.set_timer(None)
         spans = timer.totals_ms()
-        # ---- the dominant kernel on its own (outside the timed region: a bracket costs ~10 us of idle) ----
+        # ---- the dominant kernel on its own (its own pass: a bracket costs ~10 us of idle) ----
         # Same steps again with BevEncode's recorded launch list replayed in two calls, so that its LAST launch - up2:
         # x2 upsample + 3x3 conv 256 -> 128 + BN + ReLU + fused 1x1 head, 38 % of the step's FLOPs - gets a HIP-event
         # bracket of its own; profiles/r02_bench_kernel_summary.txt holds the same kernel's rocprofv3 average.
@@ -252,7 +270,7 @@ def main():
         barrier()
         dt_l1 = time.perf_counter() - t1
 
-    tmax = torch.tensor([dt, dt_l1], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt, dt_l1, dt_cold], dtype=torch.float64, device=dev)
     per_rank = [args.steps * B / dt]
     comm = {"backend": "none", "ranks": 1}
     if dist is not None:
@@ -266,7 +284,7 @@ def main():
         comm = {"backend": dist.get_backend(), "ranks": int(ones[0]),
                 "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if not rehearse else None,
                 "devices": "all ranks on cuda:0 (LSS_BENCH_REHEARSE)" if rehearse else "one GPU per rank (LOCAL_RANK)"}
-    dt, dt_l1 = float(tmax[0]), float(tmax[1])
+    dt, dt_l1, dt_cold = float(tmax[0]), float(tmax[1]), float(tmax[2])
     frames = args.steps * B * world
     fps = frames / dt
 
@@ -328,6 +346,9 @@ def main():
                         "bytes_per_step": splat_bytes_step},
         "per_rank_fps": per_rank, "comm": comm,
         "levels": {"L2_hot_path_fps": fps,
+                   "cold_start_fps": frames / dt_cold,
+                   "cold_start_note": "the same K steps timed right after the first W warm-up steps, before the "
+                                      "config.spinup_ms spin-up (device still ramping its clock)",
                    "L1_lift_splat_fps": frames / dt_l1, "L1_ms_per_step": dt_l1 / args.steps * 1e3,
                    "L1_algorithmic_GBs": l1_bytes_step * args.steps * world / dt_l1 / 1e9,
                    "L1_frac_of_hbm_peak": l1_bytes_step * args.steps / dt_l1 / 1e9 / HBM_PEAK_GBS},
@@ -337,10 +358,10 @@ def main():
     if not args.no_train and args.workload == "config2":
         # An extra, informational leg: a failure in it (every rank sees the same exception class) must not cost the
         # main metric's line, so it is reported instead of raised.
-        # ... and a HANG in it (a collective some rank never joins) must not either: every rank arms a watchdog that
-        # prints the line without the leg (rank 0) and leaves, so the launcher always sees N clean exits.
+        # ... a HANG in it (a collective some rank never joins) is different: every rank arms a watchdog that prints
+        # the line measured so far, naming the leg (rank 0), and leaves with rc = WATCHDOG_RC - never a clean exit.
         wd = _arm_watchdog(float(os.environ.get("LSS_BENCH_TRAIN_TIMEOUT", "300")),
-                           dict(out, train={"error": "watchdog: the train leg did not finish in time"}), rank)
+                           dict(out, train={"error": "watchdog: the train leg did not finish in time"}), rank, "train")
         try:
             out["train"] = train_leg(args, model, feats, calib, dev, dist, world, B)
         except Exception as e:  # noqa: BLE001
@@ -385,19 +406,26 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
-        wd = _arm_watchdog(60.0, None, -1)  # the line is out: a teardown that hangs ends in a plain exit
+        wd = _arm_watchdog(60.0, None, rank, "destroy_process_group")  # the line is out; a hung teardown is still rc != 0
         dist.destroy_process_group()
         wd.cancel()
 
 
-def _arm_watchdog(seconds, line, rank):
-    """After `seconds`: rank 0 prints `line` (the JSON object of everything measured so far) and every rank exits 0."""
+WATCHDOG_RC = 3
+
+
+def _arm_watchdog(seconds, line, rank, leg="?"):
+    """After `seconds`: rank 0 prints `line` (the JSON object of everything measured so far, with the leg that hung
+    named in it) and EVERY rank leaves with a non-zero code (WATCHDOG_RC): a hang in a process that has touched the
+    GPU must not reach the launcher as a clean exit.  No retry, no re-exec."""
     import threading
 
     def fire():
-        if rank == 0:
-            print(json.dumps(line), flush=True)
-        os._exit(0)
+        sys.stderr.write("bench.py watchdog: leg '%s' did not finish in %.0f s (rank %d)\n" % (leg, seconds, rank))
+        sys.stderr.flush()
+        if rank == 0 and line is not None:
+            print(json.dumps(dict(line, watchdog={"hung_leg": leg, "timeout_s": seconds})), flush=True)
+        os._exit(WATCHDOG_RC)
 
     t = threading.Timer(seconds, fire)
     t.daemon = True
@@ -467,8 +495,8 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
 
 
 def host_cores():
-    """Cores this process may actually use: affinity mask and cgroup CPU quota (a
-    1-GPU box exposes 256 logical CPUs but grants ~16)."""
+    """Cores this process may actually use: affinity mask and cgroup CPU quota (a 1-GPU box exposes 256 logical
+    CPUs but grants ~16).  LSS_CPU_THREADS overrides."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -476,12 +504,12 @@ def host_cores():
             n = min(n, max(1, int(int(quota) / int(period))))
     except Exception:
         pass
-    return int(os.environ.get("LSS_CPU_THREADS", min(n, 16)))
+    return int(os.environ.get("LSS_CPU_THREADS", n))
 
 
 def cpu_baseline(model, feats, calib, B):
-    """The CPU oracle (= op-for-op port of the reference's torch code) on the host
-    cores, same tensors, bounded sample: 1 warm-up + 3 timed passes of L1 and L2."""
+    """The CPU oracle (= op-for-op port of the reference's torch code) on ALL the host cores this process is granted,
+    same tensors, bounded sample: 1 warm-up + 5 timed passes of L1 and L2, median."""
     from oracle import bev_oracle as bo
     from oracle import lss_oracle as lo
     ncores = host_cores()
@@ -490,6 +518,7 @@ def cpu_baseline(model, feats, calib, B):
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     bsd = {k[len("bevencode."):]: v for k, v in sd.items() if k.startswith("bevencode.")}
     x = feats.cpu()
+    NPASS = 5
 
     def l1():
         return lo.lift_splat_torch(x, sd["camencode.depthnet.weight"], sd["camencode.depthnet.bias"], sd["frustum"],
@@ -499,16 +528,17 @@ def cpu_baseline(model, feats, calib, B):
         grid = l1()
         bo.bev_encode(grid, bsd)
         t_l1, t_l2 = [], []
-        for _ in range(3):
+        for _ in range(NPASS):
             t0 = time.perf_counter(); grid = l1(); t1 = time.perf_counter()
             bo.bev_encode(grid, bsd); t2 = time.perf_counter()
             t_l1.append(t1 - t0); t_l2.append(t2 - t0)
     t_l1.sort(); t_l2.sort()
     torch.set_num_threads(threads_before)
-    return {"value": B / t_l2[1], "unit": "frames/s", "cores": ncores, "kind": "port",
-            "sample": "3 passes of batch %d (median), fp32, full hot path; L1 (lift-splat only) = %.1f frames/s"
-                      % (B, B / t_l1[1]),
-            "L1_value": B / t_l1[1]}
+    return {"value": B / t_l2[NPASS // 2], "unit": "frames/s", "cores": ncores, "kind": "port",
+            "sample": "%d passes of batch %d (median; 1 warm-up pass before), fp32, full hot path, torch intra-op threads = "
+                      "the %d cores granted to this process; L1 (lift-splat only) = %.1f frames/s"
+                      % (NPASS, B, ncores, B / t_l1[NPASS // 2]),
+            "L1_value": B / t_l1[NPASS // 2]}
 
 
 if __name__ == "__main__":

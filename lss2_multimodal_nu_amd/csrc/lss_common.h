@@ -17,11 +17,12 @@
     if ((v) <= 0) return LSS_E_SHAPE; \
   } while (0)
 
-// Status of the launch just enqueued.  hipPeekAtLastError, not hipGetLastError: the per-thread error is
-// shared with the host framework's own HIP calls, and reading it here must not clear an error the framework
-// has yet to see (nor would clearing make a sticky error go away).
+// Status of the launch just enqueued.  hipGetLastError: a returned failure is also CLEARED, so that one failed LSS
+// launch (bad configuration, LDS size) does not stay latched in the thread and get reported again by every later
+// LSS entry - or by the host framework's next launch check, attributed to the wrong op.  The host
+// framework reads its own launches' status right after each of them, so nothing of its is pending here.
 static inline int lss_launch_status() {
-  hipError_t e = hipPeekAtLastError();
+  hipError_t e = hipGetLastError();
   return (e == hipSuccess || e == hipErrorNotReady) ? 0 : (int)e;  // NotReady: a pending event query, not a launch error
 }
 

@@ -126,8 +126,11 @@ class _HeadCEFn(torch.autograd.Function):
 def head_weighted_cross_entropy(y, head, ytgt, weight):
     """nn.CrossEntropyLoss(weight=weight)(head(y), ytgt) for a 1x1 `head` = nn.Conv2d(128, K, 1) applied to the
     (B, 128, H, W) activation y: fused into one HIP kernel per direction on the GPU when the shapes
-    fit (128 input channels, 4 or 8 classes); the two separate ops otherwise."""
-    if (y.is_cuda and y.dim() == 4 and y.shape[1] == 128 and head.kernel_size == (1, 1) and head.bias is not None
+    fit (128 input channels, 4 or 8 classes) AND y is already bf16 (autocast / bf16 precision: the kernel reads y
+    as bf16 and returns dy rounded to bf16, which for a bf16 y loses nothing).  An fp32 y (parity mode) takes the two
+    separate ops, so that `forward_loss` equals `forward` + `SimpleLoss` to fp32 accuracy, loss and gradients."""
+    if (y.is_cuda and y.dtype == torch.bfloat16 and y.dim() == 4 and y.shape[1] == 128 and head.kernel_size == (1, 1)
+            and head.bias is not None
             and head.out_channels in (4, 8) and ytgt.dtype == torch.int64
             and tuple(ytgt.shape) == (y.shape[0], y.shape[2], y.shape[3])):
         return _HeadCEFn.apply(y, head.weight, head.bias, ytgt, weight)

@@ -39,3 +39,19 @@ def test_world_size_mismatch_is_an_error():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
+
+
+def test_fired_watchdog_exits_non_zero_and_names_the_leg():
+    """a hang in a process that has touched the GPU must not be reported as success.  The watchdog prints
+    the partial line with the hung leg (rank 0) and leaves with rc != 0."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; "
+            "bench._arm_watchdog(0.2, {'metric': 'm', 'value': 1.0}, 0, 'train'); time.sleep(30)" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 3, (p.returncode, p.stderr[-300:])
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["watchdog"]["hung_leg"] == "train" and line["value"] == 1.0
+    assert "watchdog" in p.stderr
+    # a non-zero rank prints no line but leaves with the same code
+    code1 = code.replace("0, 'train'", "1, 'train'")
+    p1 = subprocess.run([sys.executable, "-c", code1], capture_output=True, text=True, timeout=120)
+    assert p1.returncode == 3 and p1.stdout.strip() == ""

@@ -557,3 +557,41 @@ def test_forward_loss_equals_forward_plus_reference_loss(variant, report):
     report("forward_loss[%s] min grad cos" % variant, worst)
     report("forward_loss[%s] max |norm ratio - 1|" % variant, worst_ratio)
     assert checked > 40
+
+
+def test_forward_loss_fp32_equals_forward_plus_simple_loss(report):
+    """with precision fp32 (parity mode) `forward_loss` must equal `forward` + `SimpleLoss` to
+    fp32 accuracy, loss AND gradients: an fp32 activation never goes through the bf16 head + cross-entropy kernel
+    (which reads y as bf16 and hands back a bf16 dy)."""
+    import copy
+    torch.manual_seed(22)
+    B = 1
+    m = L.compile_model_lss(B, GRID, AUG, 4, precision="fp32").cuda().train()
+    with torch.no_grad():
+        for blk in list(m.bevencode.layer1) + list(m.bevencode.layer2) + list(m.bevencode.layer3):
+            blk.bn2.weight.fill_(0.7)
+    m2 = copy.deepcopy(m)
+    calib = lo.synthetic_rig(B, train_aug=True, seed=5)
+    x = torch.randn(B * 6, 512, 8, 22).cuda()
+    tgt = torch.randint(0, 4, (B, 200, 200)).cuda()
+    fused = m.forward_loss(x, *calib, tgt)
+    two = L.SimpleLoss().cuda()(m2(x, *calib), tgt)
+    assert report("forward_loss fp32: |loss diff| / loss", abs(float(fused) - float(two)) / abs(float(two))) <= 1e-5
+    fused.backward()
+    two.backward()
+    worst, checked = 0.0, 0
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        if p1.grad is None or p2.grad is None:
+            assert p1.grad is None and p2.grad is None, n1
+            continue
+        a, b = p1.grad.double().flatten(), p2.grad.double().flatten()
+        if float(b.norm()) == 0:
+            continue
+        # the same fp32 ops on both sides up to the order of atomically accumulated sums (BN statistics, conv
+        # weight gradients of the library kernels): 1e-3 of the gradient's norm is ~100x below one bf16 rounding
+        rel = float((a - b).norm() / b.norm())
+        worst = max(worst, rel)
+        assert rel < 1e-3, (n1, rel)
+        checked += 1
+    report("forward_loss fp32: max grad rel-L2", worst)
+    assert checked > 40
