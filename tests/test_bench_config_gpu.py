@@ -74,7 +74,9 @@ def test_benched_step_b4_bf16_vs_oracle(report, bn):
     e_grid = report("bench_b4_grid_rel_l2_" + bn, (grid32 - ref_grid).norm() / ref_grid.norm())
     assert e_grid < 1e-3
     assert (grid32 - ref_grid).abs().max() < 1e-3 * ref_grid.abs().max()
-    assert torch.equal(grid32 == 0, ref_grid == 0)
+    # same occupied cells (element-wise zeros differ: the reference's cumsum-difference leaves exact zeros / tiny
+    # residues where the direct sum does not)
+    assert torch.equal(grid32.abs().sum(1) > 0, ref_grid.abs().sum(1) > 0)
     # the bf16 hand-off is the same sums rounded once to bf16 (2^-9 relative)
     assert (grid_bf - grid32).abs().max() <= 2.0 ** -8 * grid32.abs().max()
 
