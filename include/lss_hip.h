@@ -59,6 +59,10 @@ extern "C" {
 #define LSS_ACT_RELU 1
 #define LSS_ACT_GELU 2 /* 0.5 x (1 + erf(x / sqrt 2)), torch.nn.GELU() */
 #define LSS_OUT_F32 16
+/* lss_conv2d_fwd / lss_conv2d_head_fwd (3x3, stride 1, pad 1, bf16): `w_packed` is in the layout of
+ * lss_conv2d_pack_weights_ring and the launch runs on the loader / consumer ring kernel (csrc/conv_ring.hip);
+ * LSS_E_SHAPE when lss_conv2d_ring_ok() says the shape is not one of its cases. */
+#define LSS_W_RING 64
 /* lss_conv2d_fwd, 1x1 bf16 only: y is written head-major, (B, Cout/32, Ho*Wo, 32), the
  * layout the deformable-attention gather reads with the fewest cache lines */
 #define LSS_OUT_HEAD_MAJOR32 32
@@ -272,6 +276,16 @@ int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packed,
                    void* y, float* stats, int B, int H, int W, int Cx, int C2, int up,
                    int Cout, int KH, int KW, int stride, int pad, int relu, int dt,
                    void* stream);
+
+/* K8r  the ring kernel's weight layout for the big 3x3 / stride-1 layers (replaces the same lines as K8:
+ * src/modules.py:22-27 `Up.conv`, :110-116 `up2`): per (128-channel block, 32-channel chunk, tap) one 8-KiB slab in
+ * the consumer waves' MFMA fragment order, so that a slab is 8 coalesced 1-KiB LDS-DMA pieces.
+ * lss_conv2d_ring_ok: 1 when (B, H, W, Cx, C2, up, Cout, head_n) is a case for that kernel (head_n = 0: no head). */
+int lss_conv2d_ring_ok(int B, int H, int W, int Cx, int C2, int up, int Cout, int head_n);
+size_t lss_conv2d_ring_packed_weight_bytes(int Cout, int Cin);
+int lss_conv2d_pack_weights_ring(const float* w_oihw, int Cout, int Cin, void* w_packed, void* stream);
+/* flag waits of the ring kernel that hit their bound since load (must be 0; synchronises the device) */
+int lss_conv2d_ring_timeouts(void);
 
 /* ---------------------------------------------------------------------------
  * K8b  gradients of the convolutions (training; replaces the ConvolutionBackward autograd

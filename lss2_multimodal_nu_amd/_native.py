@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("LSS_HIP_LIB") or os.path.join(_HERE, "csrc", "liblss_
 
 BEV_NCHW_F32, BEV_NHWC_F32, BEV_NHWC_BF16 = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_GELU, OUT_F32, OUT_HEAD_MAJOR32 = 0, 1, 2, 16, 32
+ACT_NONE, ACT_RELU, ACT_GELU, OUT_F32, OUT_HEAD_MAJOR32, W_RING = 0, 1, 2, 16, 32, 64
 VALUE_NHWC, VALUE_HEAD_MAJOR = 0, 1
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
@@ -44,6 +44,10 @@ SIGNATURES = {
     "lss_conv2d_packed_weight_bytes": (_sz, [_i] * 5),
     "lss_conv2d_pack_weights": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lss_conv2d_fwd": (_i, [_vp] * 8 + [_i] * 13 + [_vp]),
+    "lss_conv2d_ring_ok": (_i, [_i] * 8),
+    "lss_conv2d_ring_packed_weight_bytes": (_sz, [_i, _i]),
+    "lss_conv2d_pack_weights_ring": (_i, [_vp, _i, _i, _vp, _vp]),
+    "lss_conv2d_ring_timeouts": (_i, []),
     "lss_conv2d_pack_weights_dgrad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lss_conv2d_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "lss_conv2d_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),

@@ -23,6 +23,7 @@ SOURCES = {
     "depthnet.hip": [],
     "splat.hip": [],
     "conv_mfma.hip": [],
+    "conv_ring.hip": [],
     "layout.hip": [],
     "bev_transformer.hip": [],
     "linear_mfma.hip": [],

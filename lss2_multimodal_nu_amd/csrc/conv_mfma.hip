@@ -24,6 +24,10 @@ int lss_linear_bf16_launch(const void* x, const void* w, const float* scale, con
                            const void* residual, void* y, long long M, int N, int K, int act,
                            int out_f32, int group_hw, hipStream_t st);  // linear_mfma.hip
 
+int lss_conv_ring_launch(const void* x, const void* x2, const void* w_ring, const float* scale, const float* shift,
+                         void* y, const float* head_w, const float* head_b, float* head_out, int head_n, int B, int H,
+                         int W, int Cx, int C2, int up, int Cout, int relu, int wt, hipStream_t st);  // conv_ring.hip
+
 namespace {
 
 constexpr bool NT_OK(int kh, int kw) { return kh * kw >= 6; }
@@ -1362,6 +1366,14 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   if (pad < 0 || C2 < 0) return LSS_E_SHAPE;
   if (dt != LSS_DT_F32 && dt != LSS_DT_BF16) return LSS_E_LAYOUT;
   if (C2 > 0 && x2 == nullptr) return LSS_E_NULL;
+  if (relu & LSS_W_RING) {  // ring-packed weights: the loader / consumer kernel, or nothing
+    if (dt != LSS_DT_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || residual != nullptr || stats != nullptr ||
+        (relu & ~(LSS_W_RING | 1)) != 0)
+      return LSS_E_SHAPE;
+    const bool wt_ring = (getenv("LSS_CONV_WT") == nullptr || atoi(getenv("LSS_CONV_WT")) != 0);
+    return lss_conv_ring_launch(x, x2, w_packed, scale, shift, y, nullptr, nullptr, nullptr, 0, B, H, W, Cx, C2, up, Cout,
+                                relu & 1, wt_ring ? 1 : 0, lss_stream(stream));
+  }
   const int kblock = dt == LSS_DT_BF16 ? 64 : 8;
   // K blocks never straddle the x2 | upsample(x) boundary
   if (Cx % kblock != 0 || C2 % kblock != 0) return LSS_E_SHAPE;
@@ -1492,6 +1504,12 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
   LSS_CHECK_PTR(out);
   LSS_CHECK_POS(B); LSS_CHECK_POS(H); LSS_CHECK_POS(W); LSS_CHECK_POS(Cx); LSS_CHECK_POS(up);
   LSS_CHECK_POS(head_n);
+  if (relu & LSS_W_RING) {
+    if ((relu & ~(LSS_W_RING | 1)) != 0) return LSS_E_SHAPE;
+    if (C2 > 0 && x2 == nullptr) return LSS_E_NULL;
+    return lss_conv_ring_launch(x, x2, w_packed, scale, shift, nullptr, head_w, head_b, out, head_n, B, H, W, Cx, C2, up,
+                                Cout, relu & 1, 0, lss_stream(stream));
+  }
   if ((Cout != 128 && Cout != 64) || C2 < 0 || Cx % 64 != 0 || C2 % 64 != 0 || head_n > 64) return LSS_E_SHAPE;
   if (Cout == 64 && (up != 1 || C2 != 0)) return LSS_E_SHAPE;  // the 64-wide tile has no fused-gather form
   if (C2 > 0 && x2 == nullptr) return LSS_E_NULL;

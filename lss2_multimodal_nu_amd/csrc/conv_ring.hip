@@ -1,0 +1,690 @@
+// K8r: the big 3x3 / stride-1 convolutions of BevEncode (up1.conv0, up1.conv3, up2 + head: 76 % of its FLOPs;
+// ref src/modules.py:9-27, 108-116) as an implicit GEMM with SPECIALISED WAVES: consumer waves that only read LDS
+// fragments and issue MFMAs, a weight-loader wave that streams the weight slabs by LDS-DMA, and a patch-loader wave
+// that gathers the input patch (plain DMA, or the fused bilinear-upsample / concat of `Up.forward`).  No workgroup
+// barrier inside the main loop: producers and consumers hand LDS buffers over through FULL / FREE words in LDS
+// (MI355X_MICROARCH.md, row 'ring-gemm'), so the four consumer waves drift against each other instead of meeting
+// at a barrier every step, and no MFMA wave ever issues a DMA piece or a blend instruction (round 2 measured the
+// weight DMA issue at 20-31 % of these kernels when the MFMA waves carry it).
+//
+// Geometry.  Output pixels are cut into STRIPS of 4 rows x 20 columns = five 4x4-pixel blocks; a block is the 16
+// columns of one v_mfma_f32_16x16x32_bf16 (A = 16 output channels x 32 input channels of the weights, B = 32 input
+// channels x 16 pixels of the patch).  100 and 200 are multiples of 20 and of 4, so the 100^2 / 200^2 layers tile
+// with NO waste (round 2's 8 x 16 tiles covered 104 x 112: +16.5 % MFMAs at 100^2), and a workgroup = 2 strips x 128
+// output channels gives 500 workgroups at 100^2 x 256 channels x batch 4 and 1000 at 200^2 x 128 channels: one / two
+// full rounds of the 512 resident slots (2 workgroups per CU), 97.6 % full.
+//   consumer wave w (0..3): strip w >> 1, channel half w & 1 -> 5 blocks x 4 channel tiles = 20 accumulators of 4
+//   registers.  The rows of channel tile t are the channels {16 q + 4 t + i}: lane (q = lane >> 4, n = lane & 15)
+//   then ends with 16 CONSECUTIVE channels of pixel n in its 16 accumulator registers of a block, and the epilogue
+//   stores 2 x 16 B per block straight from registers (no LDS staging pass; round 2: 19 % of up1.conv3).
+// K loop: chunk = 32 input channels, step = (chunk, tap): 20 MFMAs per wave against one 8-KiB weight slab.
+// LDS (78-80 KiB, two workgroups per CU):
+//   ring   NSL slots x 8 KiB  weight slab of one step in FRAGMENT ORDER (piece (cg, t, lane) at ((cg*4+t)*64+lane)*16:
+//          a consumer reads its A fragment lane-linearly = conflict-free); the packed weights in global memory have
+//          exactly this image, so a slab is 8 fully coalesced 1-KiB DMA pieces
+//   patch  2 buffers x 2 strips x (6 rows x 24 positions x 64 B): position-major, the four 16-B channel pieces of a
+//          position XOR-swizzled by (row & 1) << 1 - conflict-free ds_read_b128 for every tap shift (checked by
+//          enumeration over the hardware's b128 lane groups, tools/lds_bank_check.py)
+//   src    (fused upsample) the low-res source window of a chunk, 2 strips x 5 x 14 positions
+//   flags  FULL_W[slot] = fill count (weight loader), FREE_W[slot] = releases (consumers, LDS atomic add),
+//          FULL_P / FREE_P the same for the two patch buffers
+#include <type_traits>
+
+#include "lss_common.h"
+
+namespace {
+
+constexpr int RK_SW = 20, RK_SH = 4;          // strip: 20 x 4 output pixels
+constexpr int RK_PW = 24, RK_PH = 6;          // patch positions of a strip (22 x 6 used)
+constexpr int RK_KC = 32;                     // input channels per chunk
+constexpr int RK_POSB = RK_KC * 2;            // 64 B per patch position
+constexpr int RK_STRIP_PATCH = RK_PH * RK_PW * RK_POSB;   // 9216 B = 9 DMA pieces
+constexpr int RK_SLAB = 128 * RK_KC * 2;      // 8192 B = 8 DMA pieces
+constexpr int RK_SRC_H = 5, RK_SRC_W = 14;    // low-res source window of a strip patch (scale factors >= 2)
+constexpr int RK_SRC_STRIP = RK_SRC_H * RK_SRC_W * RK_POSB;  // 4480 B
+constexpr int RK_SPIN_LIMIT = 1 << 16;        // bound of every flag wait (~10 ms): a protocol bug must end the grid, not hang it
+
+struct RingArgs {
+  const unsigned short* x;    // (B, H, W, Cx) bf16 NHWC; the low-res source when up > 1
+  const unsigned short* x2;   // (B, Hin, Win, C2) bf16 NHWC or null
+  const unsigned char* w;     // ring-packed weights (lss_conv2d_pack_weights_ring)
+  const float* scale;
+  const float* shift;
+  unsigned short* y;          // (B, Hin, Win, Cout) bf16 NHWC (no head)
+  const float* head_w;        // (head_n, 128) fp32
+  const float* head_b;
+  float* head_out;            // (B, head_n, Hin, Win) fp32 NCHW
+  int head_n;
+  int B, H, W, Cx, C2, up, Hin, Win, Cin, Cout, relu, wt;
+  float ry, rx;
+  int SX, SY, nstrips, nblk, nch;
+};
+
+__device__ __attribute__((aligned(128))) unsigned char lss_ring_zero_page[128];  // source of out-of-image patch pieces
+__device__ int lss_ring_timeouts;  // flag waits that hit their bound (must stay 0; read by lss_conv2d_ring_timeouts)
+
+template <int MODE, bool HEAD, int NSL>
+struct RingLds {
+  static constexpr int RING = 0;
+  static constexpr int PATCH = NSL * RK_SLAB;
+  static constexpr int SRC = PATCH + 2 * 2 * RK_STRIP_PATCH;
+  static constexpr int HEADX = SRC + (MODE == 1 ? 2 * RK_SRC_STRIP : 0);
+  static constexpr int FLAGS = HEADX + (HEAD ? 2 * 80 * 4 * 4 : 0);
+  static constexpr int TOTAL = FLAGS + 256;
+};
+// flag words (ints at FLAGS)
+constexpr int F_FULL_W = 0, F_FREE_W = 8, F_FULL_P = 16, F_FREE_P = 18, F_HEAD = 20;
+
+__device__ __forceinline__ void rk_glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void rk_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void rk_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Flag words live in LDS and are addressed through address_space(3) pointers: a generic `volatile int*` made
+// hipcc emit flat_load ... sc0 sc1 followed by vmcnt(0) waits (seen in the ISA of the first build).
+typedef __attribute__((address_space(3))) volatile int* rk_flag_t;
+// wave-uniform read of a flag word
+__device__ __forceinline__ int rk_peek(rk_flag_t f) { return __builtin_amdgcn_readfirstlane(*f); }
+// wait until *f >= need (bounded)
+__device__ __forceinline__ void rk_wait_ge(rk_flag_t f, int need) {
+  int v = rk_peek(f);
+  int n = 0;
+  while (v < need) {
+    __builtin_amdgcn_s_sleep(1);
+    v = rk_peek(f);
+    if (++n > RK_SPIN_LIMIT) {
+      if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&lss_ring_timeouts, 1);
+      break;
+    }
+  }
+  asm volatile("" ::: "memory");  // nothing that reads the handed-over buffer may move above the wait
+}
+__device__ __forceinline__ void rk_set(rk_flag_t f, int v, int lane) {
+  if (lane == 0) *f = v;
+}
+// FREE counters: one no-return LDS atomic from lane 0 (inline asm: the compiler's atomic optimiser otherwise wraps
+// every add in a wave reduction; an LDS operation it does not know of only makes its counted lgkmcnt waits stricter)
+__device__ __forceinline__ void rk_add1(rk_flag_t f, int lane) {
+  if (lane == 0) {
+    const unsigned int addr = (unsigned int)(__UINTPTR_TYPE__)f;
+    asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1) : "memory");
+  }
+}
+
+// bilinear blend of four 8-channel bf16 pieces, four-weight form on (lo, hi) channel pairs (the arithmetic of
+// conv_mfma.hip's blend_bf16x8: the fused-gather layers give the same operand bits on either kernel)
+typedef __attribute__((ext_vector_type(2))) float rk_f32x2;
+__device__ __forceinline__ rk_f32x2 rk_unpack_bf2(unsigned int u) {
+  rk_f32x2 v;
+  v[0] = __builtin_bit_cast(float, u << 16);
+  v[1] = __builtin_bit_cast(float, u & 0xffff0000u);
+  return v;
+}
+__device__ __forceinline__ uint4 rk_blend(const uint4& q00, const uint4& q01, const uint4& q10, const uint4& q11,
+                                          float lx, float ly) {
+  const float w11 = lx * ly, w10 = ly - w11, w01 = lx - w11, w00 = 1.f - lx - ly + w11;
+  const unsigned int* u00 = reinterpret_cast<const unsigned int*>(&q00);
+  const unsigned int* u01 = reinterpret_cast<const unsigned int*>(&q01);
+  const unsigned int* u10 = reinterpret_cast<const unsigned int*>(&q10);
+  const unsigned int* u11 = reinterpret_cast<const unsigned int*>(&q11);
+  uint4 out;
+  unsigned int* o = reinterpret_cast<unsigned int*>(&out);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    rk_f32x2 r = rk_unpack_bf2(u00[i]) * w00;
+    r = __builtin_elementwise_fma(rk_unpack_bf2(u01[i]), (rk_f32x2){w01, w01}, r);
+    r = __builtin_elementwise_fma(rk_unpack_bf2(u10[i]), (rk_f32x2){w10, w10}, r);
+    r = __builtin_elementwise_fma(rk_unpack_bf2(u11[i]), (rk_f32x2){w11, w11}, r);
+    o[i] = lss_pack_bf2(r[0], r[1]);
+  }
+  return out;
+}
+
+struct RingTile {
+  int nb;            // 128-channel block
+  int b[2], oy0[2], ox0[2];
+  bool ok[2];
+};
+
+// MODE 0: plain NHWC input.  MODE 1: input = cat([x2, bilinear_upsample_align_corners(x, up)]) (ref Up.forward).
+template <int MODE, bool HEAD, int NSL>
+__global__ __launch_bounds__(384, 3) void conv_ring_kernel(RingArgs a) {
+  using L = RingLds<MODE, HEAD, NSL>;
+  constexpr int LA = NSL - 2;  // weight slabs in flight: one slot being consumed, one published and waiting
+  static_assert(NSL >= 3 && NSL <= 8, "ring depth");
+  static_assert(L::TOTAL <= 80 * 1024, "two workgroups per CU");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[L::TOTAL];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const rk_flag_t flags = (rk_flag_t)((__attribute__((address_space(3))) unsigned char*)smem + L::FLAGS);
+  if (tid < 64) flags[tid] = 0;
+  __syncthreads();
+
+  // ---- which tile: XCD-aware order (blocks b and b + 8 share an XCD: give each XCD a contiguous range) ----
+  RingTile T;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    T.nb = t % a.nblk;
+    const int pair = t / a.nblk;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      int sid = 2 * pair + s;
+      T.ok[s] = sid < a.nstrips;
+      sid = min(sid, a.nstrips - 1);
+      const int per = a.SX * a.SY;
+      T.b[s] = sid / per;
+      const int rem = sid - T.b[s] * per;
+      const int sy = rem / a.SX;
+      T.oy0[s] = sy * RK_SH;
+      T.ox0[s] = (rem - sy * a.SX) * RK_SW;
+    }
+  }
+  const int nsteps = a.nch * 9;
+
+  if (wave == 4) {
+    // =============================== weight loader ===============================
+    __builtin_amdgcn_s_setprio(2);
+    const unsigned char* wsrc = a.w + (size_t)T.nb * a.nch * 9 * RK_SLAB + lane * 16;
+    int slot = 0, gen = 1, pslot = 0, pgen = 1;
+    for (int i = 0; i < nsteps; ++i) {
+      if (gen > 1) rk_wait_ge(flags + F_FREE_W + slot, 4 * (gen - 1));
+      unsigned char* dst = smem + L::RING + slot * RK_SLAB;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) rk_glds16(wsrc + (size_t)i * RK_SLAB + k * 1024, dst + k * 1024);
+      if (i >= LA) {
+        rk_wait_vmcnt<8 * LA>();  // everything but the LA youngest slabs has landed
+        rk_set(flags + F_FULL_W + pslot, pgen, lane);
+        if (++pslot == NSL) { pslot = 0; ++pgen; }
+      }
+      if (++slot == NSL) { slot = 0; ++gen; }
+    }
+    rk_wait_vmcnt<0>();
+    for (int k = 0; k < LA && k < nsteps; ++k) {
+      rk_set(flags + F_FULL_W + pslot, pgen, lane);
+      if (++pslot == NSL) { pslot = 0; ++pgen; }
+    }
+    return;
+  }
+
+  if (wave == 5) {
+    // =============================== patch loader ===============================
+    __builtin_amdgcn_s_setprio(3);
+    // piece `it` = (strip it / 9, DMA block it % 9): lane -> patch position 16 * (it % 9) + (lane >> 2), 16-B slot
+    // lane & 3, which holds channel piece slot ^ ((row & 1) << 1)
+    const int nskip = MODE == 1 ? a.C2 / RK_KC : a.nch;  // chunks copied straight from a full-resolution tensor
+    const unsigned short* xfull = MODE == 1 ? a.x2 : a.x;
+    const int cfull = MODE == 1 ? a.C2 : a.Cx;
+    int poff[18];  // element offset of the piece's pixel in the full-resolution tensor (+ channel piece), or -1
+    int g_off[MODE == 1 ? 18 : 1];
+    unsigned int g_w[MODE == 1 ? 18 : 1];
+    int src_o[MODE == 1 ? 10 : 1];
+#pragma unroll
+    for (int it = 0; it < 18; ++it) {
+      const int s = it / 9, pos = (it % 9) * 16 + (lane >> 2);
+      const int prow = pos / RK_PW, pcol = pos - prow * RK_PW;
+      const int piece = (lane & 3) ^ ((prow & 1) << 1);
+      const int iy = T.oy0[s] - 1 + prow, ix = T.ox0[s] - 1 + pcol;
+      const bool in = T.ok[s] && pcol < RK_SW + 2 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+      poff[it] = (in && cfull > 0) ? ((T.b[s] * a.Hin + iy) * a.Win + ix) * cfull + piece * 8 : -1;
+      if (MODE == 1) {
+        g_off[it] = 0;
+        g_w[it] = 0;
+        if (in) {
+          const int wy0 = (int)(a.ry * (float)max(T.oy0[s] - 1, 0)), wx0 = (int)(a.rx * (float)max(T.ox0[s] - 1, 0));
+          const float sy = a.ry * (float)iy, sx = a.rx * (float)ix;
+          const int y0 = (int)sy, x0 = (int)sx;
+          const unsigned int wy = (unsigned int)((sy - (float)y0) * 65536.f + 0.5f);
+          const unsigned int wx = (unsigned int)((sx - (float)x0) * 65536.f + 0.5f);
+          g_w[it] = min(wx, 65535u) | (min(wy, 65535u) << 16);
+          const int fl = (x0 < a.W - 1 ? 1 : 0) | (y0 < a.H - 1 ? 2 : 0) | 4;
+          g_off[it] = ((((y0 - wy0) * RK_SRC_W + (x0 - wx0)) * 4 + piece) * 16) | fl;
+        }
+      }
+    }
+    if (MODE == 1) {
+#pragma unroll
+      for (int it = 0; it < 10; ++it) {
+        const int s = it / 5, q = (it % 5) * 64 + lane;
+        const int pos = min(q >> 2, RK_SRC_H * RK_SRC_W - 1), part = q & 3;
+        const int sr = pos / RK_SRC_W, sc = pos - sr * RK_SRC_W;
+        const int wy0 = (int)(a.ry * (float)max(T.oy0[s] - 1, 0)), wx0 = (int)(a.rx * (float)max(T.ox0[s] - 1, 0));
+        src_o[it] = ((T.b[s] * a.H + min(wy0 + sr, a.H - 1)) * a.W + min(wx0 + sc, a.W - 1)) * a.Cx + part * 8;
+      }
+    }
+    // full-resolution chunk c -> patch buffer `buf` by DMA (18 pieces)
+    auto issue_full = [&](int c, int buf) {
+      unsigned char* dst = smem + L::PATCH + buf * (2 * RK_STRIP_PATCH);
+#pragma unroll
+      for (int it = 0; it < 18; ++it) {
+        const void* src = poff[it] >= 0 ? (const void*)(xfull + poff[it] + c * RK_KC) : (const void*)lss_ring_zero_page;
+        rk_glds16(src, dst + it * 1024);
+      }
+    };
+    if (MODE == 0) {
+      issue_full(0, 0);
+      if (a.nch > 1) issue_full(1, 1);
+      for (int c = 0; c < a.nch; ++c) {
+        if (c + 1 < a.nch) rk_wait_vmcnt<18>();
+        else rk_wait_vmcnt<0>();
+        rk_set(flags + F_FULL_P + (c & 1), (c >> 1) + 1, lane);
+        if (c + 2 < a.nch) {
+          rk_wait_ge(flags + F_FREE_P + (c & 1), 4 * ((c >> 1) + 1));  // the consumers are done with chunk c
+          issue_full(c + 2, c & 1);
+        }
+      }
+    } else {
+      // source window of upsampled chunk c -> src (10 pieces; the last of a strip is partial)
+      auto issue_src = [&](int c) {
+        const int cx = c * RK_KC - a.C2;
+#pragma unroll
+        for (int it = 0; it < 10; ++it) {
+          const int s = it / 5, k = it % 5;
+          if (k * 64 + lane < RK_SRC_H * RK_SRC_W * 4)
+            rk_glds16(a.x + src_o[it] + cx, smem + L::SRC + s * RK_SRC_STRIP + k * 1024);
+        }
+      };
+      auto prepare = [&](int c) {  // start the DMA chunk c needs
+        if (c < nskip) {
+          rk_wait_ge(flags + F_FREE_P + (c & 1), 4 * (c >> 1));
+          issue_full(c, c & 1);
+        } else {
+          issue_src(c);
+        }
+      };
+      prepare(0);
+      for (int c = 0; c < a.nch; ++c) {
+        rk_wait_vmcnt<0>();
+        if (c >= nskip) {
+          rk_wait_ge(flags + F_FREE_P + (c & 1), 4 * (c >> 1));
+          unsigned char* dst = smem + L::PATCH + (c & 1) * (2 * RK_STRIP_PATCH);
+#pragma unroll 2
+          for (int it = 0; it < 18; ++it) {
+            const unsigned char* sp = smem + L::SRC + (it / 9) * RK_SRC_STRIP;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (g_off[it] & 4) {
+              const unsigned char* p00 = sp + (g_off[it] & ~15);
+              const int dx = (g_off[it] & 1) ? 4 * 16 : 0, dy = (g_off[it] & 2) ? RK_SRC_W * 4 * 16 : 0;
+              const uint4 q00 = *reinterpret_cast<const uint4*>(p00);
+              const uint4 q01 = *reinterpret_cast<const uint4*>(p00 + dx);
+              const uint4 q10 = *reinterpret_cast<const uint4*>(p00 + dy);
+              const uint4 q11 = *reinterpret_cast<const uint4*>(p00 + dy + dx);
+              v = rk_blend(q00, q01, q10, q11, (float)(g_w[it] & 0xffff) * (1.f / 65536.f),
+                           (float)(g_w[it] >> 16) * (1.f / 65536.f));
+            }
+            *reinterpret_cast<uint4*>(dst + it * 1024 + lane * 16) = v;
+          }
+          rk_wait_lgkm0();  // the blended pieces are in LDS, and the source window has been read
+        }
+        if (c + 1 < a.nch && c + 1 >= nskip) prepare(c + 1);  // the source window is free again
+        rk_set(flags + F_FULL_P + (c & 1), (c >> 1) + 1, lane);
+        if (c + 1 < a.nch && c + 1 < nskip) prepare(c + 1);
+      }
+    }
+    return;
+  }
+
+  // ================================== consumers ==================================
+  const int sidx = wave >> 1, cg = wave & 1;
+  const int n = lane & 15, kq = lane >> 4;
+  // this wave's strip (selects, not indexing: a runtime-indexed struct member would live in scratch)
+  const int my_b = sidx ? T.b[1] : T.b[0], my_oy0 = sidx ? T.oy0[1] : T.oy0[0], my_ox0 = sidx ? T.ox0[1] : T.ox0[0];
+  const bool my_ok = sidx ? T.ok[1] : T.ok[0];
+  // LDS byte offsets of this lane's fragments.  Pixel fragment of block j at tap (ky, kx): position (n >> 2) + ky,
+  // 4 j + (n & 3) + kx of the strip's patch, 16-B piece kq ^ ((row & 1) << 1).  The swizzle only touches bit 5 of the
+  // offset, so tap row 1 is (pb0 ^ 32) + 1536 and tap row 2 is pb0 + 3072: ONE address register, laundered through
+  // an empty asm in every step so that the compiler does not hoist a table of per-tap bases out of the loop (it did:
+  // six loop-invariant bases, spilled and reloaded inside the loop of the first build).
+  const __attribute__((address_space(3))) unsigned char* lds = (const __attribute__((address_space(3))) unsigned char*)smem;
+  f32x4 acc[5][4];
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // Fragments, all single-buffered (80 accumulator + 16 weight + 20 pixel registers: the 168-register budget of
+  // three waves per SIMD with room to spare, and no buffer parity, so the chunk loop stays rolled).  A step runs in
+  // two phases of 10 MFMAs: phase A = channel tiles 0, 1 over the five blocks, phase B = tiles 2, 3.  Weight
+  // fragments 2, 3 of THIS slab are requested at the top of the step (used in phase B), fragments 0, 1 of the NEXT
+  // slab between the phases (used at the top of the next step), and the pixel fragment of block j for the next step
+  // right behind block j's phase-B MFMAs: every request is 10 MFMAs (>= 160 cycles) ahead of its use.
+  // The fragment reads and their waits are inline asm: left to itself hipcc put ONE s_waitcnt lgkmcnt(0) in front of
+  // phase A (every build tried), i.e. each step waited for reads it had issued two instructions earlier.  The LDS
+  // queue of a wave is in order and its content per step is fixed -
+  //     fw0' fw1' flag' (add) fp0' .. fp4' (add at tap 8) | fw2 fw3 | phase A | fw0" fw1" flag" | phase B ...
+  // - so block j of phase A needs `lgkmcnt(6 - j)` (the 4 - j younger pixel fragments and fw2, fw3 may still be in
+  // flight) and phase B `lgkmcnt(3)`.  The waits take the fragments they cover as read-write operands, which is what
+  // keeps the MFMAs behind them (cdna_hip_programming.md section 5.4 rule 18).
+  bf16x8 fw[4], fp[5];
+#define RK_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+  // the lane id recomputed where an address is formed (2 VALU), so that no address register lives across the MFMAs
+  auto lane_now = [&]() {
+    int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+  };
+  auto w_addr = [&](int slot) { return L::RING + cg * 4096 + lane_now() * 16 + slot * RK_SLAB; };
+  auto p_addr = [&](int buf, auto TAPc) {
+    constexpr int TAP = decltype(TAPc)::value;
+    const int l = lane_now(), n_ = l & 15, kq_ = l >> 4;
+    int p = (((n_ >> 2) * RK_PW + (n_ & 3)) * RK_POSB + (kq_ << 4)) ^ (((n_ >> 2) & 1) << 5);
+    if (TAP / 3 == 1) p ^= 32;
+    return p + (L::PATCH + sidx * RK_STRIP_PATCH) + buf * (2 * RK_STRIP_PATCH);
+  };
+  const unsigned int flag_base = (unsigned int)(__UINTPTR_TYPE__)flags;
+
+  int slot = 0, gen = 1, buf = 0, pgen = 1;
+  rk_wait_ge(flags + F_FULL_P + 0, 1);
+  rk_wait_ge(flags + F_FULL_W + 0, 1);
+  int fnext;  // FULL word of the next step's slot, read one step ahead
+  {
+    const int wa = w_addr(0), pa = p_addr(0, std::integral_constant<int, 0>{});
+    RK_DSR(fw[0], wa, 0);
+    RK_DSR(fw[1], wa, 1024);
+    asm volatile("ds_read_b32 %0, %1" : "=v"(fnext) : "v"(flag_base + 4 * (F_FULL_W + (1 % NSL))));
+    RK_DSR(fp[0], pa, 0 * 4 * RK_POSB);
+    RK_DSR(fp[1], pa, 1 * 4 * RK_POSB);
+    RK_DSR(fp[2], pa, 2 * 4 * RK_POSB);
+    RK_DSR(fp[3], pa, 3 * 4 * RK_POSB);
+    RK_DSR(fp[4], pa, 4 * 4 * RK_POSB);
+  }
+
+  auto step = [&](auto TAPc, bool last) {
+    constexpr int TAP = decltype(TAPc)::value;
+    constexpr int NT = (TAP + 1) % 9;
+    constexpr int POFF = (NT / 3) * (RK_PW * RK_POSB) + (NT % 3) * RK_POSB;  // tap offset of the next step's pixel fragments
+    int nslot = slot + 1, ngen = gen;
+    if (nslot == NSL) { nslot = 0; ++ngen; }
+    int nbuf = buf, npgen = pgen;
+    if (TAP == 8) {
+      nbuf = buf ^ 1;
+      if (nbuf == 0) ++npgen;
+    }
+    {
+      const int wa = w_addr(slot);
+      RK_DSR(fw[2], wa, 2048);
+      RK_DSR(fw[3], wa, 3072);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // phase A
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fw[0]), "+v"(fw[1]), "+v"(fp[0]));
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0], fp[0], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1], fp[0], acc[0][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fp[1]));
+    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0], fp[1], acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1], fp[1], acc[1][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fp[2]));
+    acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0], fp[2], acc[2][0], 0, 0, 0);
+    acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1], fp[2], acc[2][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fp[3]));
+    acc[3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0], fp[3], acc[3][0], 0, 0, 0);
+    acc[3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1], fp[3], acc[3][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fp[4]));
+    acc[4][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0], fp[4], acc[4][0], 0, 0, 0);
+    acc[4][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1], fp[4], acc[4][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    int pa = 0;
+    if (!last) {
+      // the next step's slab (and, at the last tap, the next chunk's patch) must have been published; the FULL word
+      // was read a step ago, ahead of fragments phase A has waited for
+      if (__builtin_amdgcn_readfirstlane(fnext) < ngen) rk_wait_ge(flags + F_FULL_W + nslot, ngen);
+      if (TAP == 8) rk_wait_ge(flags + F_FULL_P + nbuf, npgen);
+      asm volatile("" ::: "memory");
+      const int wa = w_addr(nslot);
+      RK_DSR(fw[0], wa, 0);
+      RK_DSR(fw[1], wa, 1024);
+      const int n2 = nslot + 1 == NSL ? 0 : nslot + 1;
+      asm volatile("ds_read_b32 %0, %1" : "=v"(fnext) : "v"(flag_base + 4 * (F_FULL_W + n2)));
+      pa = p_addr(nbuf, std::integral_constant<int, NT>{});
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fw[2]), "+v"(fw[3]));
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fw[2]), "+v"(fw[3]));
+    }
+    // phase B: behind block j's MFMAs the pixel fragment of block j is requested for the next step
+    acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[2], fp[0], acc[0][2], 0, 0, 0);
+    acc[0][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[3], fp[0], acc[0][3], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    rk_add1(flags + F_FREE_W + slot, lane);  // the wave has waited for fragments 2, 3: every read of this slab is done
+    if (!last) RK_DSR(fp[0], pa, POFF + 0 * 4 * RK_POSB);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[2], fp[1], acc[1][2], 0, 0, 0);
+    acc[1][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[3], fp[1], acc[1][3], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!last) RK_DSR(fp[1], pa, POFF + 1 * 4 * RK_POSB);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[2][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[2], fp[2], acc[2][2], 0, 0, 0);
+    acc[2][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[3], fp[2], acc[2][3], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!last) RK_DSR(fp[2], pa, POFF + 2 * 4 * RK_POSB);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[3][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[2], fp[3], acc[3][2], 0, 0, 0);
+    acc[3][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[3], fp[3], acc[3][3], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!last) RK_DSR(fp[3], pa, POFF + 3 * 4 * RK_POSB);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[4][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[2], fp[4], acc[4][2], 0, 0, 0);
+    acc[4][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[3], fp[4], acc[4][3], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!last) RK_DSR(fp[4], pa, POFF + 4 * 4 * RK_POSB);
+    // behind the last block every pixel fragment of this chunk has arrived (phase A waited for them)
+    if (TAP == 8) rk_add1(flags + F_FREE_P + buf, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    slot = nslot; gen = ngen; buf = nbuf; pgen = npgen;
+  };
+  for (int c = 0; c < a.nch; ++c) {
+    step(std::integral_constant<int, 0>{}, false);
+    step(std::integral_constant<int, 1>{}, false);
+    step(std::integral_constant<int, 2>{}, false);
+    step(std::integral_constant<int, 3>{}, false);
+    step(std::integral_constant<int, 4>{}, false);
+    step(std::integral_constant<int, 5>{}, false);
+    step(std::integral_constant<int, 6>{}, false);
+    step(std::integral_constant<int, 7>{}, false);
+    step(std::integral_constant<int, 8>{}, c + 1 == a.nch);
+  }
+#undef RK_DSR
+
+  // ---- epilogue: lane (q = kq, n) holds channels ch0 .. ch0 + 15 of pixel n of every block ----
+  const int ch0 = T.nb * 128 + cg * 64 + kq * 16;
+  {
+    float sc[16], sh[16];
+#pragma unroll
+    for (int v4 = 0; v4 < 4; ++v4) {
+      f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, h4 = {0.f, 0.f, 0.f, 0.f};
+      if (a.scale) s4 = *reinterpret_cast<const f32x4*>(a.scale + ch0 + v4 * 4);
+      if (a.shift) h4 = *reinterpret_cast<const f32x4*>(a.shift + ch0 + v4 * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sc[v4 * 4 + i] = s4[i]; sh[v4 * 4 + i] = h4[i]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = acc[j][t][i] * sc[t * 4 + i] + sh[t * 4 + i];
+          acc[j][t][i] = a.relu ? fmaxf(v, 0.f) : v;
+        }
+  }
+  const int oy = my_oy0 + (n >> 2);
+  if (!HEAD) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.y, 0, a.wt ? (int)((size_t)a.B * a.Hin * a.Win * a.Cout * 2) : 0, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int ox = my_ox0 + j * 4 + (n & 3);
+      if (!my_ok || oy >= a.Hin || ox >= a.Win) continue;
+      const size_t o = (((size_t)my_b * a.Hin + oy) * a.Win + ox) * a.Cout + ch0;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        u32x4 ov;
+        ov[0] = lss_pack_bf2(acc[j][2 * hf][0], acc[j][2 * hf][1]);
+        ov[1] = lss_pack_bf2(acc[j][2 * hf][2], acc[j][2 * hf][3]);
+        ov[2] = lss_pack_bf2(acc[j][2 * hf + 1][0], acc[j][2 * hf + 1][1]);
+        ov[3] = lss_pack_bf2(acc[j][2 * hf + 1][2], acc[j][2 * hf + 1][3]);
+        if (a.wt) __builtin_amdgcn_raw_buffer_store_b128(ov, yrsrc, (int)((o + hf * 8) * 2), 0, 16);  // write-through
+        else *reinterpret_cast<u32x4*>(a.y + o + hf * 8) = ov;
+      }
+    }
+  } else {
+    // fused 1x1 head (ref src/modules.py:115, up2[4]) in fp32 on the VALU: logits[k] = head_b[k] + sum_c act[c] * head_w[k][c].
+    // A lane sums its 16 channels, the four q lanes of a pixel and the two channel-half waves add up (shuffles,
+    // then one exchange through LDS); lane (q, n) of the cg = 0 wave ends with class q of pixel n.
+    float part[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) part[j] = 0.f;
+    const int c0 = cg * 64 + kq * 16;  // channel of the 128-wide head input (Cout == 128)
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      float hw[16];
+#pragma unroll
+      for (int v4 = 0; v4 < 4; ++v4) {
+        f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
+        if (k < a.head_n) w4 = *reinterpret_cast<const f32x4*>(a.head_w + (size_t)k * 128 + c0 + v4 * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hw[v4 * 4 + i] = w4[i];
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s = fmaf(acc[j][t][i], hw[t * 4 + i], s);
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (kq == k) part[j] = s;  // every q lane holds the sum over the wave's 64 channels; keep class q
+      }
+    }
+    float* hx = reinterpret_cast<float*>(smem + L::HEADX) + sidx * (80 * 4);
+    if (cg == 1) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) hx[(j * 16 + n) * 4 + kq] = part[j];
+      rk_wait_lgkm0();
+      rk_set(flags + F_HEAD + sidx, 1, lane);
+    } else {
+      rk_wait_ge(flags + F_HEAD + sidx, 1);
+      if (kq < a.head_n) {
+        const float hb = a.head_b[kq];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int ox = my_ox0 + j * 4 + (n & 3);
+          const float v = part[j] + hx[(j * 16 + n) * 4 + kq] + hb;
+          if (my_ok && oy < a.Hin && ox < a.Win)
+            a.head_out[(((size_t)my_b * a.head_n + kq) * a.Hin + oy) * a.Win + ox] = v;
+        }
+      }
+    }
+  }
+}
+
+// OIHW fp32 -> ring layout bf16: slab (nb, chunk, tap) = 8 KiB, piece (cg, t, l) at ((cg*4+t)*64+l)*16 B holds
+// W[co = nb*128 + cg*64 + ((l&15)>>2)*16 + 4t + (l&3)][ci = chunk*32 + (l>>4)*8 .. +8][tap]
+__global__ void pack_weights_ring_kernel(const float* __restrict__ w, int Cout, int Cin, unsigned short* __restrict__ out) {
+  const size_t n = (size_t)Cout * Cin * 9;
+  const int nch = Cin / RK_KC;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int j = e & 7;
+    size_t r = e >> 3;
+    const int l = r & 63; r >>= 6;
+    const int t = r & 3; r >>= 2;
+    const int cg = r & 1; r >>= 1;
+    const int tap = r % 9; r /= 9;
+    const int chunk = r % nch;
+    const int nb = r / nch;
+    const int co = nb * 128 + cg * 64 + ((l & 15) >> 2) * 16 + 4 * t + (l & 3);
+    const int ci = chunk * RK_KC + (l >> 4) * 8 + j;
+    out[e] = lss_f2bf(w[((size_t)co * Cin + ci) * 9 + tap]);
+  }
+}
+
+}  // namespace
+
+// Is (shape) a case for the ring kernel?  3x3 / stride 1 / pad 1, bf16, Cout a multiple of 128, channel counts of
+// both inputs multiples of 32 (the chunk), scale factor 1 (no skip tensor) or
+// >= 2 (source window), head: Cout == 128 and at most 4 classes; and enough pixels for the strips to fill the chip.
+extern "C" int lss_conv2d_ring_ok(int B, int H, int W, int Cx, int C2, int up, int Cout, int head_n) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cx <= 0 || C2 < 0 || up <= 0 || Cout <= 0 || head_n < 0) return 0;
+  if (Cout % 128 != 0 || Cx % 32 != 0 || C2 % 32 != 0) return 0;
+  if (head_n > 0 && (Cout != 128 || head_n > 4)) return 0;
+  const bool fused = up > 1 || C2 > 0;
+  const int Hin = H * up, Win = W * up;
+  if (fused) {
+    if (up < 2) return 0;
+    const float ry = Hin > 1 ? (float)(H - 1) / (float)(Hin - 1) : 0.f, rx = Win > 1 ? (float)(W - 1) / (float)(Win - 1) : 0.f;
+    // the 6 x 22 patch of a strip must interpolate from a 5 x 14 source window
+    if ((int)(ry * (RK_PH - 1) + 0.999f) + 2 > RK_SRC_H || (int)(rx * (RK_SW + 1) + 0.999f) + 2 > RK_SRC_W) return 0;
+  }
+  if ((long long)B * Hin * Win * (long long)Cout >= (1LL << 31) / 2) return 0;
+  if ((long long)B * H * W * (long long)Cx >= (1LL << 31) || (long long)B * Hin * Win * (long long)(C2 > 0 ? C2 : 1) >= (1LL << 31))
+    return 0;
+  const long long strips = (long long)B * lss_cdiv(Hin, RK_SH) * lss_cdiv(Win, RK_SW);
+  return strips / 2 * (Cout / 128) >= 192 ? 1 : 0;
+}
+
+// Number of flag waits of the ring kernel that ran into their bound since the module was loaded (synchronises the
+// device).  Anything but 0 means a hand-off protocol error: the affected launches produced garbage.
+extern "C" int lss_conv2d_ring_timeouts(void) {
+  int v = -1;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(lss_ring_timeouts), sizeof(int), 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return v;
+}
+
+extern "C" size_t lss_conv2d_ring_packed_weight_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0 || Cout % 128 != 0 || Cin % RK_KC != 0) return 0;
+  return (size_t)Cout * Cin * 9 * 2;
+}
+
+extern "C" int lss_conv2d_pack_weights_ring(const float* w_oihw, int Cout, int Cin, void* w_packed, void* stream) {
+  LSS_CHECK_PTR(w_oihw); LSS_CHECK_PTR(w_packed);
+  if (lss_conv2d_ring_packed_weight_bytes(Cout, Cin) == 0) return LSS_E_SHAPE;
+  const size_t n = (size_t)Cout * Cin * 9;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(pack_weights_ring_kernel, dim3(grid), dim3(256), 0, lss_stream(stream), w_oihw, Cout, Cin,
+                     reinterpret_cast<unsigned short*>(w_packed));
+  return lss_launch_status();
+}
+
+// launcher shared by lss_conv2d_fwd / lss_conv2d_head_fwd (conv_mfma.hip) when the weights are ring-packed
+int lss_conv_ring_launch(const void* x, const void* x2, const void* w_ring, const float* scale, const float* shift,
+                         void* y, const float* head_w, const float* head_b, float* head_out, int head_n, int B, int H,
+                         int W, int Cx, int C2, int up, int Cout, int relu, int wt, hipStream_t st) {
+  if (!lss_conv2d_ring_ok(B, H, W, Cx, C2, up, Cout, head_n)) return LSS_E_SHAPE;
+  if (relu != 0 && relu != 1) return LSS_E_LAYOUT;
+  RingArgs a;
+  a.x = reinterpret_cast<const unsigned short*>(x);
+  a.x2 = reinterpret_cast<const unsigned short*>(x2);
+  a.w = reinterpret_cast<const unsigned char*>(w_ring);
+  a.scale = scale; a.shift = shift;
+  a.y = reinterpret_cast<unsigned short*>(y);
+  a.head_w = head_w; a.head_b = head_b; a.head_out = head_out; a.head_n = head_n;
+  a.B = B; a.H = H; a.W = W; a.Cx = Cx; a.C2 = C2; a.up = up;
+  a.Hin = H * up; a.Win = W * up; a.Cin = Cx + C2; a.Cout = Cout; a.relu = relu; a.wt = wt;
+  a.ry = a.Hin > 1 ? (float)(H - 1) / (float)(a.Hin - 1) : 0.f;
+  a.rx = a.Win > 1 ? (float)(W - 1) / (float)(a.Win - 1) : 0.f;
+  a.SX = lss_cdiv(a.Win, RK_SW); a.SY = lss_cdiv(a.Hin, RK_SH);
+  a.nstrips = B * a.SX * a.SY;
+  a.nblk = Cout / 128;
+  a.nch = a.Cin / RK_KC;
+  const bool fused = up > 1 || C2 > 0;
+  const dim3 g((a.nstrips + 1) / 2 * a.nblk), blk(384);
+  if (head_n > 0) {
+    if (fused) hipLaunchKernelGGL((conv_ring_kernel<1, true, 4>), g, blk, 0, st, a);
+    else hipLaunchKernelGGL((conv_ring_kernel<0, true, 5>), g, blk, 0, st, a);
+  } else {
+    if (fused) hipLaunchKernelGGL((conv_ring_kernel<1, false, 4>), g, blk, 0, st, a);
+    else hipLaunchKernelGGL((conv_ring_kernel<0, false, 5>), g, blk, 0, st, a);
+  }
+  return lss_launch_status();
+}

@@ -355,6 +355,31 @@ class _FoldedConv:
         self.pad_in = pad_in
         self.key = None
         self.w = self.scale = self.shift = None
+        self.w_ring, self.ring_key = None, None
+
+    def ring(self, dt):
+        """The same weights in the ring kernel's layout (csrc/conv_ring.hip), packed on first use and whenever a
+        source tensor changes; `get(dt)` must have been called for the current key."""
+        if self.ring_key != self.key:
+            with torch.no_grad():
+                w32 = self.conv.weight.detach().float().contiguous()
+                if self.pad_in is not None:
+                    at, n = self.pad_in
+                    w32 = torch.cat([w32[:, :at], w32.new_zeros(w32.shape[0], n, *w32.shape[2:]), w32[:, at:]],
+                                    1).contiguous()
+                self.w_ring = ops.pack_conv_weight_ring(w32)
+            self.ring_key = self.key
+        return self.w_ring
+
+    def ring_case(self, x, dt, residual=None, x2=None, up=1, head_n=0):
+        """Does this call go to the loader / consumer ring kernel?  3x3 / stride 1 / pad 1, bf16, no residual, and a
+        shape `lss_conv2d_ring_ok` accepts (the three big layers of BevEncode at the benchmark sizes)."""
+        c = self.conv
+        if (dt != ops.DT_BF16 or residual is not None or c.kernel_size != (3, 3) or c.stride != (1, 1)
+                or c.padding != (1, 1) or not self.pack):
+            return False
+        B, H, W, Cx = x.shape
+        return ops.conv_ring_ok(B, H, W, Cx, x2.shape[3] if x2 is not None else 0, up, c.out_channels, head_n)
 
     def _key(self, dt):
         # (storage pointer, in-place version) of every tensor the folded form depends on
@@ -408,6 +433,8 @@ class _FoldedConv:
         c = self.conv
         if self._s2d(dt) and x2 is None and up == 1:
             return ops.conv2d_s2_nhwc(x, w, c.kernel_size[0], c.padding[0], scale, shift, residual, relu)
+        if relu in (False, True) and self.ring_case(x, dt, residual, x2, up):
+            w = self.ring(dt)
         return ops.conv2d_nhwc(x, w, c.kernel_size, c.stride[0], c.padding[0], scale, shift, residual, relu,
                                x2=x2, up=up, dt=dt)
 
@@ -741,6 +768,8 @@ class BevEncode(nn.Module):
             # up2: x2 upsample + 3x3 conv + BN + ReLU + 1x1 head in ONE launch, NCHW fp32 out
             w, scale, shift = self._up2a.get(dt)
             head = self.up2[4]
+            if self._up2a.ring_case(x, dt, up=2, head_n=head.out_channels):
+                w = self._up2a.ring(dt)
             hw = head.weight.detach().float().reshape(head.out_channels, -1).contiguous()
             return ops.conv3x3_head_nchw(x, w, scale, shift, hw, head.bias.detach().float().contiguous(), up=2)
         x = self._up2a.run(x, dt, relu=True, up=2)

@@ -4,11 +4,13 @@ Each function validates shapes/dtypes on the host (a mis-shaped operand must
 never reach a kernel), allocates outputs with torch, and enqueues the kernel on
 torch's current HIP stream.  No CPU / eager fallbacks exist here.
 """
+import os
+
 import torch
 
 from . import _native as N
 from ._native import (ACT_GELU, ACT_NONE, ACT_RELU, BEV_NCHW_F32, BEV_NHWC_BF16, BEV_NHWC_F32, DT_BF16,  # noqa: F401
-                      DT_F32, OUT_F32, OUT_HEAD_MAJOR32, VALUE_HEAD_MAJOR, VALUE_NHWC)
+                      DT_F32, OUT_F32, OUT_HEAD_MAJOR32, VALUE_HEAD_MAJOR, VALUE_NHWC, W_RING)
 
 
 def _f32c(t, name, shape=None):
@@ -536,6 +538,34 @@ def pack_conv_weight(w_oihw, dt):
     return out
 
 
+class RingWeight:
+    """3x3 weights in the loader / consumer ring kernel's layout (csrc/conv_ring.hip): `data` is the flat bf16
+    image, `Cout`, `Cin` the logical shape."""
+
+    def __init__(self, data, Cout, Cin):
+        self.data, self.Cout, self.Cin = data, Cout, Cin
+
+
+def conv_ring_ok(B, H, W, Cx, C2, up, Cout, head_n=0):
+    """Is this 3x3 / stride-1 / pad-1 bf16 conv a case for the ring kernel (lss_conv2d_ring_ok)?"""
+    if os.environ.get("LSS_CONV_RING") == "0":
+        return False
+    return bool(N.lib().lss_conv2d_ring_ok(B, H, W, Cx, C2, up, Cout, head_n))
+
+
+def pack_conv_weight_ring(w_oihw):
+    """OIHW fp32 (3x3) -> RingWeight."""
+    Cout, Cin, KH, KW = w_oihw.shape
+    _f32c(w_oihw, "conv weight")
+    nbytes = N.lib().lss_conv2d_ring_packed_weight_bytes(Cout, Cin)
+    if (KH, KW) != (3, 3) or nbytes == 0:
+        raise ValueError("ring weights: 3x3, Cout % 128 == 0, Cin % 32 == 0 (got %s)" % (tuple(w_oihw.shape),))
+    out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w_oihw.device)
+    N.check(N.lib().lss_conv2d_pack_weights_ring(N.ptr(w_oihw), Cout, Cin, N.ptr(out), N.stream()),
+            "lss_conv2d_pack_weights_ring")
+    return RingWeight(out, Cout, Cin)
+
+
 def conv2d_nhwc(x, w_packed, ksize, stride, pad, scale=None, shift=None, residual=None, relu=False,
                 x2=None, up=1, stats=None, dt=DT_BF16, tag="conv2d_fwd", out_f32=False, head_major=False):
     """K8.  x (B,H,W,Cx) NHWC in `dt`; x2 (B,H*up,W*up,C2) optional skip tensor
@@ -546,7 +576,11 @@ def conv2d_nhwc(x, w_packed, ksize, stride, pad, scale=None, shift=None, residua
     act = int(relu) | (OUT_F32 if (out_f32 and dt == DT_BF16) else 0) | (OUT_HEAD_MAJOR32 if head_major else 0)
     B, H, W, Cx = x.shape
     KH, KW = ksize
-    taps, Cout, Cin = w_packed.shape
+    if isinstance(w_packed, RingWeight):  # the ring kernel's layout (3x3 / s1 / p1 bf16 only; the C side checks)
+        act |= W_RING
+        taps, Cout, Cin, w_packed = 9, w_packed.Cout, w_packed.Cin, w_packed.data
+    else:
+        taps, Cout, Cin = w_packed.shape
     C2 = 0
     if x.dtype != tdt or not x.is_contiguous() or w_packed.dtype != tdt or not w_packed.is_contiguous():
         raise ValueError("conv operands must be contiguous %s" % tdt)
@@ -951,7 +985,11 @@ def conv3x3_head_nchw(x, w_packed, scale, shift, head_w, head_b, x2=None, up=1, 
     x (B,H,W,Cx) bf16 NHWC; head_w (n,Cout) fp32, Cout = 128 (64: plain 3x3 only); returns (B, n, H*up, W*up)
     fp32 NCHW."""
     B, H, W, Cx = x.shape
-    taps, Cout, Cin = w_packed.shape
+    ring = isinstance(w_packed, RingWeight)
+    if ring:
+        taps, Cout, Cin, w_packed = 9, w_packed.Cout, w_packed.Cin, w_packed.data
+    else:
+        taps, Cout, Cin = w_packed.shape
     C2 = x2.shape[3] if x2 is not None else 0
     if x.dtype != torch.bfloat16 or not x.is_contiguous() or taps != 9 or Cin != Cx + C2 or Cout not in (64, 128) \
             or (Cout == 64 and (up != 1 or C2 != 0)):
@@ -966,11 +1004,13 @@ def conv3x3_head_nchw(x, w_packed, scale, shift, head_w, head_b, x2=None, up=1, 
     if _recorder is not None:
         _recorder.add(2, (x, x2, w_packed, scale, shift, head_w, head_b, out), x=x, x2=x2, w=w_packed, scale=scale,
                       shift=shift, head_w=head_w, head_b=head_b, head_out=out, B=B, H=H, W=W, Cx=Cx, C2=C2, up=up,
-                      Cout=Cout, KH=3, KW=3, stride=1, pad=1, relu=1 if relu else 0, dt=DT_BF16, head_n=n)
+                      Cout=Cout, KH=3, KW=3, stride=1, pad=1, relu=(1 if relu else 0) | (W_RING if ring else 0),
+                      dt=DT_BF16, head_n=n)
     with _timed(tag):
         N.check(N.lib().lss_conv2d_head_fwd(N.ptr(x), N.ptr(x2), N.ptr(w_packed), N.ptr(scale), N.ptr(shift),
                                             N.ptr(head_w), N.ptr(head_b), N.ptr(out), B, H, W, Cx, C2, up, Cout, n,
-                                            1 if relu else 0, N.stream()), "lss_conv2d_head_fwd")
+                                            (1 if relu else 0) | (W_RING if ring else 0), N.stream()),
+                "lss_conv2d_head_fwd")
     return out
 
 
