@@ -23,7 +23,7 @@ SOURCES = {
     "depthnet.hip": [],
     "splat.hip": [],
     "conv_mfma.hip": [],
-    "conv_ring.hip": [],
+    "conv_ring.hip": ["-fno-slp-vectorize"],  # no v_pk_*_f32 next to MFMAs (MI355X_MICROARCH.md)
     "layout.hip": [],
     "bev_transformer.hip": [],
     "linear_mfma.hip": [],
@@ -71,7 +71,7 @@ def build(force=False, verbose=True, save_temps=False):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)
-    if procs or force or not os.path.exists(LIB):
+    if procs or force or not os.path.exists(LIB) or any(_newer(o, LIB) for o in objs if os.path.exists(o)):
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)

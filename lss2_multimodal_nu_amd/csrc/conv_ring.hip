@@ -28,6 +28,8 @@
 //   src    (fused upsample) the low-res source window of a chunk, 2 strips x 5 x 14 positions
 //   flags  FULL_W[slot] = fill count (weight loader), FREE_W[slot] = releases (consumers, LDS atomic add),
 //          FULL_P / FREE_P the same for the two patch buffers
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "lss_common.h"
@@ -58,6 +60,9 @@ struct RingArgs {
   int B, H, W, Cx, C2, up, Hin, Win, Cin, Cout, relu, wt;
   float ry, rx;
   int SX, SY, nstrips, nblk, nch;
+  // diagnostics (LSS_RING_STATS=<hex device address>): per workgroup 6 waves x 4 u64: {polls spent waiting on the
+  // first / second kind of flag, 100-MHz ticks from kernel entry to the wave's end, ticks at entry}
+  unsigned long long* stats;
 };
 
 __device__ __attribute__((aligned(128))) unsigned char lss_ring_zero_page[128];  // source of out-of-image patch pieces
@@ -67,13 +72,13 @@ template <int MODE, bool HEAD, int NSL>
 struct RingLds {
   static constexpr int RING = 0;
   static constexpr int PATCH = NSL * RK_SLAB;
-  static constexpr int SRC = PATCH + 2 * 2 * RK_STRIP_PATCH;
-  static constexpr int HEADX = SRC + (MODE == 1 ? 2 * RK_SRC_STRIP : 0);
-  static constexpr int FLAGS = HEADX + (HEAD ? 2 * 80 * 4 * 4 : 0);
+  static constexpr int SRC = PATCH + 2 * 4 * RK_STRIP_PATCH;           // two buffers x four strips
+  static constexpr int HEADX = SRC + (MODE == 1 ? 4 * RK_SRC_STRIP : 0);
+  static constexpr int FLAGS = HEADX + (HEAD ? 4 * 80 * 4 * 4 : 0);
   static constexpr int TOTAL = FLAGS + 256;
 };
 // flag words (ints at FLAGS)
-constexpr int F_FULL_W = 0, F_FREE_W = 8, F_FULL_P = 16, F_FREE_P = 18, F_HEAD = 20;
+constexpr int F_FULL_W = 0, F_FREE_W = 8, F_FULL_P = 16, F_FREE_P = 18, F_HEAD = 20, F_FULL_S = 24, F_FREE_S = 25;
 
 __device__ __forceinline__ void rk_glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -91,7 +96,7 @@ typedef __attribute__((address_space(3))) volatile int* rk_flag_t;
 // wave-uniform read of a flag word
 __device__ __forceinline__ int rk_peek(rk_flag_t f) { return __builtin_amdgcn_readfirstlane(*f); }
 // wait until *f >= need (bounded)
-__device__ __forceinline__ void rk_wait_ge(rk_flag_t f, int need) {
+__device__ __forceinline__ int rk_wait_ge(rk_flag_t f, int need) {
   int v = rk_peek(f);
   int n = 0;
   while (v < need) {
@@ -103,6 +108,7 @@ __device__ __forceinline__ void rk_wait_ge(rk_flag_t f, int need) {
     }
   }
   asm volatile("" ::: "memory");  // nothing that reads the handed-over buffer may move above the wait
+  return n;
 }
 __device__ __forceinline__ void rk_set(rk_flag_t f, int v, int lane) {
   if (lane == 0) *f = v;
@@ -116,14 +122,17 @@ __device__ __forceinline__ void rk_add1(rk_flag_t f, int lane) {
   }
 }
 
-// bilinear blend of four 8-channel bf16 pieces, four-weight form on (lo, hi) channel pairs (the arithmetic of
-// conv_mfma.hip's blend_bf16x8: the fused-gather layers give the same operand bits on either kernel)
+// bilinear blend of four 8-channel bf16 pieces in the four-weight form: r = q00 w00, then fma(q01, w01, r), fma(q10,
+// w10, r), fma(q11, w11, r) per channel - the operation order of conv_mfma.hip's blend_bf16x8, so the fused-gather
+// layers see the same operand bits on either kernel.  Written with SCALAR v_fma_f32 (the file is compiled with
+// -fno-slp-vectorize): packed f32 VALU issued next to MFMAs costs ~20 cycles more per v_pk_fma_f32 than the two plain
+// FMAs it replaces (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'), and the blend runs on SIMDs whose other
+// two waves issue MFMAs back to back; one v_cvt_pk_bf16_f32 per channel pair.
 typedef __attribute__((ext_vector_type(2))) float rk_f32x2;
-__device__ __forceinline__ rk_f32x2 rk_unpack_bf2(unsigned int u) {
-  rk_f32x2 v;
-  v[0] = __builtin_bit_cast(float, u << 16);
-  v[1] = __builtin_bit_cast(float, u & 0xffff0000u);
-  return v;
+typedef __attribute__((ext_vector_type(2))) __bf16 rk_bf16x2;
+__device__ __forceinline__ unsigned int rk_pack_bf2(float lo, float hi) {
+  const rk_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, rk_bf16x2));
 }
 __device__ __forceinline__ uint4 rk_blend(const uint4& q00, const uint4& q01, const uint4& q10, const uint4& q11,
                                           float lx, float ly) {
@@ -136,34 +145,66 @@ __device__ __forceinline__ uint4 rk_blend(const uint4& q00, const uint4& q01, co
   unsigned int* o = reinterpret_cast<unsigned int*>(&out);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    rk_f32x2 r = rk_unpack_bf2(u00[i]) * w00;
-    r = __builtin_elementwise_fma(rk_unpack_bf2(u01[i]), (rk_f32x2){w01, w01}, r);
-    r = __builtin_elementwise_fma(rk_unpack_bf2(u10[i]), (rk_f32x2){w10, w10}, r);
-    r = __builtin_elementwise_fma(rk_unpack_bf2(u11[i]), (rk_f32x2){w11, w11}, r);
-    o[i] = lss_pack_bf2(r[0], r[1]);
+    float lo = __builtin_bit_cast(float, u00[i] << 16) * w00;
+    float hi = __builtin_bit_cast(float, u00[i] & 0xffff0000u) * w00;
+    lo = __builtin_fmaf(__builtin_bit_cast(float, u01[i] << 16), w01, lo);
+    hi = __builtin_fmaf(__builtin_bit_cast(float, u01[i] & 0xffff0000u), w01, hi);
+    lo = __builtin_fmaf(__builtin_bit_cast(float, u10[i] << 16), w10, lo);
+    hi = __builtin_fmaf(__builtin_bit_cast(float, u10[i] & 0xffff0000u), w10, hi);
+    lo = __builtin_fmaf(__builtin_bit_cast(float, u11[i] << 16), w11, lo);
+    hi = __builtin_fmaf(__builtin_bit_cast(float, u11[i] & 0xffff0000u), w11, hi);
+    o[i] = rk_pack_bf2(lo, hi);
   }
   return out;
 }
 
+constexpr int RK_NS = 4;              // strips per workgroup
+constexpr int RK_NCONS = 2 * RK_NS;   // consumer waves: (strip, 64-channel half)
+constexpr int RK_NPATCH = 3;          // patch-loader waves
+constexpr int RK_NWAVES = RK_NCONS + 1 + RK_NPATCH;  // 12 = three per SIMD: ONE workgroup per CU
+constexpr int RK_NPIECE = RK_NS * 9;  // 1-KiB pieces of one patch buffer (all strips)
+
 struct RingTile {
   int nb;            // 128-channel block
-  int b[2], oy0[2], ox0[2];
-  bool ok[2];
+  int b[RK_NS], oy0[RK_NS], ox0[RK_NS];
+  bool ok[RK_NS];
 };
 
 // MODE 0: plain NHWC input.  MODE 1: input = cat([x2, bilinear_upsample_align_corners(x, up)]) (ref Up.forward).
+//
+// One workgroup per CU: 12 waves = 8 consumers (4 strips x 2 channel halves), 1 weight loader, 3 patch loaders, i.e.
+// three waves on every SIMD.  (The first version ran two 6-wave workgroups per CU - on paper: the wait statistics
+// showed half of the workgroups STARTING when the other half had finished.  Six waves land on the four SIMDs as
+// 2, 2, 1, 1 and a second workgroup only fits next to that when its own 2, 2, 1, 1 happens to fall the other way
+// round.)  A weight slab now feeds four strips instead of two: half the weight bytes streamed into LDS per MFMA.
 template <int MODE, bool HEAD, int NSL>
-__global__ __launch_bounds__(384, 3) void conv_ring_kernel(RingArgs a) {
+__global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a) {
   using L = RingLds<MODE, HEAD, NSL>;
-  constexpr int LA = NSL - 2;  // weight slabs in flight: one slot being consumed, one published and waiting
+  constexpr int LA = NSL - 2;  // weight slabs in flight at most: one slot is being consumed, one is published and waiting
   static_assert(NSL >= 3 && NSL <= 8, "ring depth");
-  static_assert(L::TOTAL <= 80 * 1024, "two workgroups per CU");
+  static_assert(L::TOTAL <= 160 * 1024, "LDS of one CU");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[L::TOTAL];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const rk_flag_t flags = (rk_flag_t)((__attribute__((address_space(3))) unsigned char*)smem + L::FLAGS);
   if (tid < 64) flags[tid] = 0;
   __syncthreads();
+  // wait statistics: a diagnostic build only (-DRK_STATS, tools/ring_stats.py); the shipped kernel carries none of it
+  int st0 = 0, st1 = 0;  // polls spent in the two kinds of waits of this wave's role (dead code without RK_STATS)
+#ifdef RK_STATS
+#define RK_ST(x) x
+  const unsigned long long t_entry = a.stats ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  auto write_stats = [&]() {
+    if (a.stats != nullptr && lane == 0) {
+      unsigned long long* o = a.stats + ((size_t)blockIdx.x * RK_NWAVES + wave) * 4;
+      o[0] = (unsigned long long)st0; o[1] = (unsigned long long)st1;
+      o[2] = __builtin_amdgcn_s_memrealtime() - t_entry; o[3] = t_entry;
+    }
+  };
+#else
+#define RK_ST(x)
+  auto write_stats = [&]() {};
+#endif
 
   // ---- which tile: XCD-aware order (blocks b and b + 8 share an XCD: give each XCD a contiguous range) ----
   RingTile T;
@@ -172,10 +213,10 @@ __global__ __launch_bounds__(384, 3) void conv_ring_kernel(RingArgs a) {
     const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     T.nb = t % a.nblk;
-    const int pair = t / a.nblk;
+    const int quad = t / a.nblk;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      int sid = 2 * pair + s;
+    for (int s = 0; s < RK_NS; ++s) {
+      int sid = RK_NS * quad + s;
       T.ok[s] = sid < a.nstrips;
       sid = min(sid, a.nstrips - 1);
       const int per = a.SX * a.SY;
@@ -188,113 +229,167 @@ __global__ __launch_bounds__(384, 3) void conv_ring_kernel(RingArgs a) {
   }
   const int nsteps = a.nch * 9;
 
-  if (wave == 4) {
+  if (wave == RK_NCONS) {
     // =============================== weight loader ===============================
     __builtin_amdgcn_s_setprio(2);
     const unsigned char* wsrc = a.w + (size_t)T.nb * a.nch * 9 * RK_SLAB + lane * 16;
-    int slot = 0, gen = 1, pslot = 0, pgen = 1;
+    // Policy: issue a slab whenever its slot is free (at most LA + 1 in flight); while the next slot is NOT free, wait
+    // for the OLDEST slab in flight only (a counted vmcnt: the wave blocks for what is left of that slab's latency,
+    // not for the whole queue), publish it, look again.  History: build 1 published slab i - LA when it issued slab i -
+    // the consumers got slab s + 5 only after releasing slab s + 3, half a step before they needed it (603 TF on
+    // up1.conv3); build 2 drained the whole queue (vmcnt(0)) before blocking on FREE.
+    int slot = 0, gen = 1, pslot = 0, pgen = 1, inflight = 0;  // inflight = issued, not yet published
+    auto publish_oldest = [&]() {
+      switch (inflight) {  // all but the inflight - 1 youngest slabs have landed
+        case 1: rk_wait_vmcnt<0>(); break;
+        case 2: rk_wait_vmcnt<8>(); break;
+        case 3: rk_wait_vmcnt<16>(); break;
+        case 4: rk_wait_vmcnt<24>(); break;
+        case 5: rk_wait_vmcnt<32>(); break;
+        case 6: rk_wait_vmcnt<40>(); break;
+        default: rk_wait_vmcnt<48>(); break;
+      }
+      rk_set(flags + F_FULL_W + pslot, pgen, lane);
+      if (++pslot == NSL) { pslot = 0; ++pgen; }
+      --inflight;
+    };
     for (int i = 0; i < nsteps; ++i) {
-      if (gen > 1) rk_wait_ge(flags + F_FREE_W + slot, 4 * (gen - 1));
+      if (gen > 1) {
+        int spins = 0;
+        while (rk_peek(flags + F_FREE_W + slot) < RK_NCONS * (gen - 1)) {
+          if (inflight > 0) {
+            publish_oldest();
+          } else {
+            __builtin_amdgcn_s_sleep(1);
+            ++st0;
+            if (++spins > RK_SPIN_LIMIT) {
+              if (lane == 0) atomicAdd(&lss_ring_timeouts, 1);
+              break;
+            }
+          }
+        }
+        asm volatile("" ::: "memory");
+      }
       unsigned char* dst = smem + L::RING + slot * RK_SLAB;
 #pragma unroll
       for (int k = 0; k < 8; ++k) rk_glds16(wsrc + (size_t)i * RK_SLAB + k * 1024, dst + k * 1024);
-      if (i >= LA) {
-        rk_wait_vmcnt<8 * LA>();  // everything but the LA youngest slabs has landed
-        rk_set(flags + F_FULL_W + pslot, pgen, lane);
-        if (++pslot == NSL) { pslot = 0; ++pgen; }
-      }
+      ++inflight;
+      if (inflight > LA) publish_oldest();
       if (++slot == NSL) { slot = 0; ++gen; }
     }
-    rk_wait_vmcnt<0>();
-    for (int k = 0; k < LA && k < nsteps; ++k) {
-      rk_set(flags + F_FULL_W + pslot, pgen, lane);
-      if (++pslot == NSL) { pslot = 0; ++pgen; }
-    }
+    while (inflight > 0) publish_oldest();
+    write_stats();
     return;
   }
 
-  if (wave == 5) {
-    // =============================== patch loader ===============================
+  if (wave > RK_NCONS) {
+    // =============================== patch loaders ===============================
+    // Patch loader p takes the 1-KiB pieces it = p, p + 3, ... of a patch buffer (12 of 36).  Piece it = (strip it / 9,
+    // block it % 9): lane -> patch position 16 * (it % 9) + (lane >> 2), 16-B slot lane & 3, which holds channel piece
+    // slot ^ ((row & 1) << 1).  FULL_P / FREE_S etc. are counters: every patch loader adds its share.
     __builtin_amdgcn_s_setprio(3);
-    // piece `it` = (strip it / 9, DMA block it % 9): lane -> patch position 16 * (it % 9) + (lane >> 2), 16-B slot
-    // lane & 3, which holds channel piece slot ^ ((row & 1) << 1)
+    const int pw = wave - RK_NCONS - 1;
+    constexpr int NIT = RK_NPIECE / RK_NPATCH;  // 12
     const int nskip = MODE == 1 ? a.C2 / RK_KC : a.nch;  // chunks copied straight from a full-resolution tensor
     const unsigned short* xfull = MODE == 1 ? a.x2 : a.x;
     const int cfull = MODE == 1 ? a.C2 : a.Cx;
-    int poff[18];  // element offset of the piece's pixel in the full-resolution tensor (+ channel piece), or -1
-    int g_off[MODE == 1 ? 18 : 1];
-    unsigned int g_w[MODE == 1 ? 18 : 1];
-    int src_o[MODE == 1 ? 10 : 1];
+    int poff[NIT];  // element offset of the piece's pixel in the full-resolution tensor (+ channel piece), or -1
+    int g_off[MODE == 1 ? NIT : 1];
+    unsigned int g_w[MODE == 1 ? NIT : 1];
+    constexpr int NSRC = MODE == 1 ? (RK_NS * 5 + RK_NPATCH - 1) / RK_NPATCH : 1;  // source-window pieces of this wave (7)
+    int src_o[NSRC];
 #pragma unroll
-    for (int it = 0; it < 18; ++it) {
+    for (int k = 0; k < NIT; ++k) {
+      const int it = pw + k * RK_NPATCH;
       const int s = it / 9, pos = (it % 9) * 16 + (lane >> 2);
       const int prow = pos / RK_PW, pcol = pos - prow * RK_PW;
       const int piece = (lane & 3) ^ ((prow & 1) << 1);
-      const int iy = T.oy0[s] - 1 + prow, ix = T.ox0[s] - 1 + pcol;
-      const bool in = T.ok[s] && pcol < RK_SW + 2 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-      poff[it] = (in && cfull > 0) ? ((T.b[s] * a.Hin + iy) * a.Win + ix) * cfull + piece * 8 : -1;
+      const int sb = s == 0 ? T.b[0] : s == 1 ? T.b[1] : s == 2 ? T.b[2] : T.b[3];
+      const int soy = s == 0 ? T.oy0[0] : s == 1 ? T.oy0[1] : s == 2 ? T.oy0[2] : T.oy0[3];
+      const int sox = s == 0 ? T.ox0[0] : s == 1 ? T.ox0[1] : s == 2 ? T.ox0[2] : T.ox0[3];
+      const bool sok = s == 0 ? T.ok[0] : s == 1 ? T.ok[1] : s == 2 ? T.ok[2] : T.ok[3];
+      const int iy = soy - 1 + prow, ix = sox - 1 + pcol;
+      const bool in = sok && pcol < RK_SW + 2 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+      poff[k] = (in && cfull > 0) ? ((sb * a.Hin + iy) * a.Win + ix) * cfull + piece * 8 : -1;
       if (MODE == 1) {
-        g_off[it] = 0;
-        g_w[it] = 0;
+        g_off[k] = 0;
+        g_w[k] = 0;
         if (in) {
-          const int wy0 = (int)(a.ry * (float)max(T.oy0[s] - 1, 0)), wx0 = (int)(a.rx * (float)max(T.ox0[s] - 1, 0));
+          const int wy0 = (int)(a.ry * (float)max(soy - 1, 0)), wx0 = (int)(a.rx * (float)max(sox - 1, 0));
           const float sy = a.ry * (float)iy, sx = a.rx * (float)ix;
           const int y0 = (int)sy, x0 = (int)sx;
           const unsigned int wy = (unsigned int)((sy - (float)y0) * 65536.f + 0.5f);
           const unsigned int wx = (unsigned int)((sx - (float)x0) * 65536.f + 0.5f);
-          g_w[it] = min(wx, 65535u) | (min(wy, 65535u) << 16);
+          g_w[k] = min(wx, 65535u) | (min(wy, 65535u) << 16);
           const int fl = (x0 < a.W - 1 ? 1 : 0) | (y0 < a.H - 1 ? 2 : 0) | 4;
-          g_off[it] = ((((y0 - wy0) * RK_SRC_W + (x0 - wx0)) * 4 + piece) * 16) | fl;
+          g_off[k] = ((((y0 - wy0) * RK_SRC_W + (x0 - wx0)) * 4 + piece) * 16) | fl;
         }
       }
     }
     if (MODE == 1) {
 #pragma unroll
-      for (int it = 0; it < 10; ++it) {
-        const int s = it / 5, q = (it % 5) * 64 + lane;
+      for (int k = 0; k < NSRC; ++k) {
+        const int it = pw + k * RK_NPATCH;  // source piece it = (strip it / 5, block it % 5); it >= 20: none
+        const int s = min(it / 5, RK_NS - 1), q = (it % 5) * 64 + lane;
         const int pos = min(q >> 2, RK_SRC_H * RK_SRC_W - 1), part = q & 3;
         const int sr = pos / RK_SRC_W, sc = pos - sr * RK_SRC_W;
-        const int wy0 = (int)(a.ry * (float)max(T.oy0[s] - 1, 0)), wx0 = (int)(a.rx * (float)max(T.ox0[s] - 1, 0));
-        src_o[it] = ((T.b[s] * a.H + min(wy0 + sr, a.H - 1)) * a.W + min(wx0 + sc, a.W - 1)) * a.Cx + part * 8;
+        const int sb = s == 0 ? T.b[0] : s == 1 ? T.b[1] : s == 2 ? T.b[2] : T.b[3];
+        const int soy = s == 0 ? T.oy0[0] : s == 1 ? T.oy0[1] : s == 2 ? T.oy0[2] : T.oy0[3];
+        const int sox = s == 0 ? T.ox0[0] : s == 1 ? T.ox0[1] : s == 2 ? T.ox0[2] : T.ox0[3];
+        const int wy0 = (int)(a.ry * (float)max(soy - 1, 0)), wx0 = (int)(a.rx * (float)max(sox - 1, 0));
+        src_o[k] = ((sb * a.H + min(wy0 + sr, a.H - 1)) * a.W + min(wx0 + sc, a.W - 1)) * a.Cx + part * 8;
       }
     }
-    // full-resolution chunk c -> patch buffer `buf` by DMA (18 pieces)
+    // this wave's pieces of full-resolution chunk c -> patch buffer `buf` by DMA
     auto issue_full = [&](int c, int buf) {
-      unsigned char* dst = smem + L::PATCH + buf * (2 * RK_STRIP_PATCH);
+      unsigned char* dst = smem + L::PATCH + buf * (RK_NS * RK_STRIP_PATCH);
 #pragma unroll
-      for (int it = 0; it < 18; ++it) {
-        const void* src = poff[it] >= 0 ? (const void*)(xfull + poff[it] + c * RK_KC) : (const void*)lss_ring_zero_page;
-        rk_glds16(src, dst + it * 1024);
+      for (int k = 0; k < NIT; ++k) {
+        const void* src = poff[k] >= 0 ? (const void*)(xfull + poff[k] + c * RK_KC) : (const void*)lss_ring_zero_page;
+        rk_glds16(src, dst + (pw + k * RK_NPATCH) * 1024);
       }
     };
     if (MODE == 0) {
+      // Chunk c + 1 is published BEFORE this wave blocks on the consumers' release of chunk c: they ask for chunk
+      // c + 1 in the middle of chunk c's last step and release chunk c at its end (the first build waited for the
+      // release first - a circular wait that only the spin bound resolved).
       issue_full(0, 0);
-      if (a.nch > 1) issue_full(1, 1);
+      if (a.nch > 1) {
+        issue_full(1, 1);
+        rk_wait_vmcnt<NIT>();
+      } else {
+        rk_wait_vmcnt<0>();
+      }
+      rk_add1(flags + F_FULL_P + 0, lane);
       for (int c = 0; c < a.nch; ++c) {
-        if (c + 1 < a.nch) rk_wait_vmcnt<18>();
-        else rk_wait_vmcnt<0>();
-        rk_set(flags + F_FULL_P + (c & 1), (c >> 1) + 1, lane);
+        if (c + 1 < a.nch) {
+          rk_wait_vmcnt<0>();
+          rk_add1(flags + F_FULL_P + ((c + 1) & 1), lane);
+        }
         if (c + 2 < a.nch) {
-          rk_wait_ge(flags + F_FREE_P + (c & 1), 4 * ((c >> 1) + 1));  // the consumers are done with chunk c
+          st0 += rk_wait_ge(flags + F_FREE_P + (c & 1), RK_NCONS * ((c >> 1) + 1));  // the consumers are done with chunk c
           issue_full(c + 2, c & 1);
         }
       }
     } else {
-      // source window of upsampled chunk c -> src (10 pieces; the last of a strip is partial)
+      // this wave's pieces of the source window of upsampled chunk c -> src (the last piece of a strip is partial)
       auto issue_src = [&](int c) {
         const int cx = c * RK_KC - a.C2;
 #pragma unroll
-        for (int it = 0; it < 10; ++it) {
-          const int s = it / 5, k = it % 5;
-          if (k * 64 + lane < RK_SRC_H * RK_SRC_W * 4)
-            rk_glds16(a.x + src_o[it] + cx, smem + L::SRC + s * RK_SRC_STRIP + k * 1024);
+        for (int k = 0; k < NSRC; ++k) {
+          const int it = pw + k * RK_NPATCH;
+          if (it < RK_NS * 5 && (it % 5) * 64 + lane < RK_SRC_H * RK_SRC_W * 4)
+            rk_glds16(a.x + src_o[k] + cx, smem + L::SRC + (it / 5) * RK_SRC_STRIP + (it % 5) * 1024);
         }
       };
-      auto prepare = [&](int c) {  // start the DMA chunk c needs
+      // start the DMA chunk c needs.  Full-resolution chunk: straight into patch buffer c & 1 once the consumers have
+      // released it; upsampled chunk: the source window, once ALL patch loaders have finished blending from it.
+      auto prepare = [&](int c) {
         if (c < nskip) {
-          rk_wait_ge(flags + F_FREE_P + (c & 1), 4 * (c >> 1));
+          st0 += rk_wait_ge(flags + F_FREE_P + (c & 1), RK_NCONS * (c >> 1));
           issue_full(c, c & 1);
         } else {
+          st1 += rk_wait_ge(flags + F_FREE_S, RK_NPATCH * (c - nskip));
           issue_src(c);
         }
       };
@@ -302,31 +397,51 @@ __global__ __launch_bounds__(384, 3) void conv_ring_kernel(RingArgs a) {
       for (int c = 0; c < a.nch; ++c) {
         rk_wait_vmcnt<0>();
         if (c >= nskip) {
-          rk_wait_ge(flags + F_FREE_P + (c & 1), 4 * (c >> 1));
-          unsigned char* dst = smem + L::PATCH + (c & 1) * (2 * RK_STRIP_PATCH);
-#pragma unroll 2
-          for (int it = 0; it < 18; ++it) {
-            const unsigned char* sp = smem + L::SRC + (it / 9) * RK_SRC_STRIP;
+          // every loader's share of the source window has landed / the consumers have released the patch buffer
+          rk_add1(flags + F_FULL_S, lane);
+          st1 += rk_wait_ge(flags + F_FULL_S, RK_NPATCH * (c - nskip + 1));
+          st0 += rk_wait_ge(flags + F_FREE_P + (c & 1), RK_NCONS * (c >> 1));
+          unsigned char* dst = smem + L::PATCH + (c & 1) * (RK_NS * RK_STRIP_PATCH);
+          // fully unrolled (static register indices for g_off / g_w), no branches (a piece outside the image blends
+          // whatever sits at offset 0 of the window and is replaced by zeros afterwards), and the four corner reads of
+          // piece k + 1 are requested before piece k is blended
+          uint4 qa[4], qb[4];
+          auto corners = [&](int k, uint4* q) {
+            const int it = pw + k * RK_NPATCH;
+            const unsigned char* p00 = smem + L::SRC + (it / 9) * RK_SRC_STRIP + (g_off[k] & 0xfff0);
+            const int dx = (g_off[k] & 1) ? 4 * 16 : 0, dy = (g_off[k] & 2) ? RK_SRC_W * 4 * 16 : 0;
+            q[0] = *reinterpret_cast<const uint4*>(p00);
+            q[1] = *reinterpret_cast<const uint4*>(p00 + dx);
+            q[2] = *reinterpret_cast<const uint4*>(p00 + dy);
+            q[3] = *reinterpret_cast<const uint4*>(p00 + dy + dx);
+          };
+          auto finish = [&](int k, const uint4* q) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (g_off[it] & 4) {
-              const unsigned char* p00 = sp + (g_off[it] & ~15);
-              const int dx = (g_off[it] & 1) ? 4 * 16 : 0, dy = (g_off[it] & 2) ? RK_SRC_W * 4 * 16 : 0;
-              const uint4 q00 = *reinterpret_cast<const uint4*>(p00);
-              const uint4 q01 = *reinterpret_cast<const uint4*>(p00 + dx);
-              const uint4 q10 = *reinterpret_cast<const uint4*>(p00 + dy);
-              const uint4 q11 = *reinterpret_cast<const uint4*>(p00 + dy + dx);
-              v = rk_blend(q00, q01, q10, q11, (float)(g_w[it] & 0xffff) * (1.f / 65536.f),
-                           (float)(g_w[it] >> 16) * (1.f / 65536.f));
-            }
-            *reinterpret_cast<uint4*>(dst + it * 1024 + lane * 16) = v;
+#ifndef RK_DIAG_NOBLEND  // timing-only build: the upsampled patch stays zero
+            v = rk_blend(q[0], q[1], q[2], q[3], (float)(g_w[k] & 0xffff) * (1.f / 65536.f),
+                         (float)(g_w[k] >> 16) * (1.f / 65536.f));
+            const bool in = (g_off[k] & 4) != 0;
+            v.x = in ? v.x : 0u; v.y = in ? v.y : 0u; v.z = in ? v.z : 0u; v.w = in ? v.w : 0u;
+#endif
+            *reinterpret_cast<uint4*>(dst + (pw + k * RK_NPATCH) * 1024 + lane * 16) = v;
+          };
+          corners(0, qa);
+#pragma unroll
+          for (int k = 0; k < NIT; k += 2) {
+            corners(k + 1, qb);
+            finish(k, qa);
+            if (k + 2 < NIT) corners(k + 2, qa);
+            finish(k + 1, qb);
           }
-          rk_wait_lgkm0();  // the blended pieces are in LDS, and the source window has been read
+          rk_wait_lgkm0();  // the blended pieces are in LDS, and this wave's reads of the source window are done
+          rk_add1(flags + F_FREE_S, lane);
         }
-        if (c + 1 < a.nch && c + 1 >= nskip) prepare(c + 1);  // the source window is free again
-        rk_set(flags + F_FULL_P + (c & 1), (c >> 1) + 1, lane);
+        if (c + 1 < a.nch && c + 1 >= nskip) prepare(c + 1);  // the next source window, as soon as this one is free
+        rk_add1(flags + F_FULL_P + (c & 1), lane);
         if (c + 1 < a.nch && c + 1 < nskip) prepare(c + 1);
       }
     }
+    write_stats();
     return;
   }
 
@@ -334,21 +449,21 @@ __global__ __launch_bounds__(384, 3) void conv_ring_kernel(RingArgs a) {
   const int sidx = wave >> 1, cg = wave & 1;
   const int n = lane & 15, kq = lane >> 4;
   // this wave's strip (selects, not indexing: a runtime-indexed struct member would live in scratch)
-  const int my_b = sidx ? T.b[1] : T.b[0], my_oy0 = sidx ? T.oy0[1] : T.oy0[0], my_ox0 = sidx ? T.ox0[1] : T.ox0[0];
-  const bool my_ok = sidx ? T.ok[1] : T.ok[0];
+  const int my_b = sidx == 0 ? T.b[0] : sidx == 1 ? T.b[1] : sidx == 2 ? T.b[2] : T.b[3];
+  const int my_oy0 = sidx == 0 ? T.oy0[0] : sidx == 1 ? T.oy0[1] : sidx == 2 ? T.oy0[2] : T.oy0[3];
+  const int my_ox0 = sidx == 0 ? T.ox0[0] : sidx == 1 ? T.ox0[1] : sidx == 2 ? T.ox0[2] : T.ox0[3];
+  const bool my_ok = sidx == 0 ? T.ok[0] : sidx == 1 ? T.ok[1] : sidx == 2 ? T.ok[2] : T.ok[3];
   // LDS byte offsets of this lane's fragments.  Pixel fragment of block j at tap (ky, kx): position (n >> 2) + ky,
   // 4 j + (n & 3) + kx of the strip's patch, 16-B piece kq ^ ((row & 1) << 1).  The swizzle only touches bit 5 of the
-  // offset, so tap row 1 is (pb0 ^ 32) + 1536 and tap row 2 is pb0 + 3072: ONE address register, laundered through
-  // an empty asm in every step so that the compiler does not hoist a table of per-tap bases out of the loop (it did:
-  // six loop-invariant bases, spilled and reloaded inside the loop of the first build).
-  const __attribute__((address_space(3))) unsigned char* lds = (const __attribute__((address_space(3))) unsigned char*)smem;
+  // offset, so tap row 1 is (p ^ 32) + 1536 and tap row 2 is p + 3072: ONE lane-dependent address, recomputed from the
+  // lane id where it is needed (a table of per-tap bases hoisted out of the loop was spilled by the first builds).
   f32x4 acc[5][4];
 #pragma unroll
   for (int j = 0; j < 5; ++j)
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // Fragments, all single-buffered (80 accumulator + 16 weight + 20 pixel registers: the 168-register budget of
-  // three waves per SIMD with room to spare, and no buffer parity, so the chunk loop stays rolled).  A step runs in
+  // three waves per SIMD, and no buffer parity, so the chunk loop stays rolled).  A step runs in
   // two phases of 10 MFMAs: phase A = channel tiles 0, 1 over the five blocks, phase B = tiles 2, 3.  Weight
   // fragments 2, 3 of THIS slab are requested at the top of the step (used in phase B), fragments 0, 1 of the NEXT
   // slab between the phases (used at the top of the next step), and the pixel fragment of block j for the next step
@@ -362,7 +477,6 @@ __global__ __launch_bounds__(384, 3) void conv_ring_kernel(RingArgs a) {
   // keeps the MFMAs behind them (cdna_hip_programming.md section 5.4 rule 18).
   bf16x8 fw[4], fp[5];
 #define RK_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-  // the lane id recomputed where an address is formed (2 VALU), so that no address register lives across the MFMAs
   auto lane_now = [&]() {
     int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(l));
@@ -374,12 +488,12 @@ __global__ __launch_bounds__(384, 3) void conv_ring_kernel(RingArgs a) {
     const int l = lane_now(), n_ = l & 15, kq_ = l >> 4;
     int p = (((n_ >> 2) * RK_PW + (n_ & 3)) * RK_POSB + (kq_ << 4)) ^ (((n_ >> 2) & 1) << 5);
     if (TAP / 3 == 1) p ^= 32;
-    return p + (L::PATCH + sidx * RK_STRIP_PATCH) + buf * (2 * RK_STRIP_PATCH);
+    return p + (L::PATCH + sidx * RK_STRIP_PATCH) + buf * (RK_NS * RK_STRIP_PATCH);
   };
   const unsigned int flag_base = (unsigned int)(__UINTPTR_TYPE__)flags;
 
   int slot = 0, gen = 1, buf = 0, pgen = 1;
-  rk_wait_ge(flags + F_FULL_P + 0, 1);
+  rk_wait_ge(flags + F_FULL_P + 0, RK_NPATCH);
   rk_wait_ge(flags + F_FULL_W + 0, 1);
   int fnext;  // FULL word of the next step's slot, read one step ahead
   {
@@ -436,8 +550,8 @@ __global__ __launch_bounds__(384, 3) void conv_ring_kernel(RingArgs a) {
     if (!last) {
       // the next step's slab (and, at the last tap, the next chunk's patch) must have been published; the FULL word
       // was read a step ago, ahead of fragments phase A has waited for
-      if (__builtin_amdgcn_readfirstlane(fnext) < ngen) rk_wait_ge(flags + F_FULL_W + nslot, ngen);
-      if (TAP == 8) rk_wait_ge(flags + F_FULL_P + nbuf, npgen);
+      if (__builtin_amdgcn_readfirstlane(fnext) < ngen) st0 += 1 + rk_wait_ge(flags + F_FULL_W + nslot, ngen);
+      if (TAP == 8) st1 += rk_wait_ge(flags + F_FULL_P + nbuf, RK_NPATCH * npgen);
       asm volatile("" ::: "memory");
       const int wa = w_addr(nslot);
       RK_DSR(fw[0], wa, 0);
@@ -493,6 +607,7 @@ __global__ __launch_bounds__(384, 3) void conv_ring_kernel(RingArgs a) {
     step(std::integral_constant<int, 8>{}, c + 1 == a.nch);
   }
 #undef RK_DSR
+  RK_ST(if (a.stats != nullptr && lane == 0) a.stats[((size_t)blockIdx.x * RK_NWAVES + wave) * 4 + 2] = __builtin_amdgcn_s_memrealtime() - t_entry;)  // end of the main loop
 
   // ---- epilogue: lane (q = kq, n) holds channels ch0 .. ch0 + 15 of pixel n of every block ----
   const int ch0 = T.nb * 128 + cg * 64 + kq * 16;
@@ -529,10 +644,10 @@ __global__ __launch_bounds__(384, 3) void conv_ring_kernel(RingArgs a) {
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         u32x4 ov;
-        ov[0] = lss_pack_bf2(acc[j][2 * hf][0], acc[j][2 * hf][1]);
-        ov[1] = lss_pack_bf2(acc[j][2 * hf][2], acc[j][2 * hf][3]);
-        ov[2] = lss_pack_bf2(acc[j][2 * hf + 1][0], acc[j][2 * hf + 1][1]);
-        ov[3] = lss_pack_bf2(acc[j][2 * hf + 1][2], acc[j][2 * hf + 1][3]);
+        ov[0] = rk_pack_bf2(acc[j][2 * hf][0], acc[j][2 * hf][1]);
+        ov[1] = rk_pack_bf2(acc[j][2 * hf][2], acc[j][2 * hf][3]);
+        ov[2] = rk_pack_bf2(acc[j][2 * hf + 1][0], acc[j][2 * hf + 1][1]);
+        ov[3] = rk_pack_bf2(acc[j][2 * hf + 1][2], acc[j][2 * hf + 1][3]);
         if (a.wt) __builtin_amdgcn_raw_buffer_store_b128(ov, yrsrc, (int)((o + hf * 8) * 2), 0, 16);  // write-through
         else *reinterpret_cast<u32x4*>(a.y + o + hf * 8) = ov;
       }
@@ -587,6 +702,11 @@ __global__ __launch_bounds__(384, 3) void conv_ring_kernel(RingArgs a) {
       }
     }
   }
+  RK_ST(if (a.stats != nullptr && lane == 0) {
+    unsigned long long* o = a.stats + ((size_t)blockIdx.x * RK_NWAVES + wave) * 4;
+    o[0] = (unsigned long long)st0; o[1] = (unsigned long long)st1; o[3] = t_entry;
+  })
+#undef RK_ST
 }
 
 // OIHW fp32 -> ring layout bf16: slab (nb, chunk, tap) = 8 KiB, piece (cg, t, l) at ((cg*4+t)*64+l)*16 B holds
@@ -630,7 +750,7 @@ extern "C" int lss_conv2d_ring_ok(int B, int H, int W, int Cx, int C2, int up, i
   if ((long long)B * H * W * (long long)Cx >= (1LL << 31) || (long long)B * Hin * Win * (long long)(C2 > 0 ? C2 : 1) >= (1LL << 31))
     return 0;
   const long long strips = (long long)B * lss_cdiv(Hin, RK_SH) * lss_cdiv(Win, RK_SW);
-  return strips / 2 * (Cout / 128) >= 192 ? 1 : 0;
+  return strips / RK_NS * (Cout / 128) >= 128 ? 1 : 0;
 }
 
 // Number of flag waits of the ring kernel that ran into their bound since the module was loaded (synchronises the
@@ -677,14 +797,18 @@ int lss_conv_ring_launch(const void* x, const void* x2, const void* w_ring, cons
   a.nstrips = B * a.SX * a.SY;
   a.nblk = Cout / 128;
   a.nch = a.Cin / RK_KC;
+  {
+    const char* e = getenv("LSS_RING_STATS");
+    a.stats = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 16)) : nullptr;
+  }
   const bool fused = up > 1 || C2 > 0;
-  const dim3 g((a.nstrips + 1) / 2 * a.nblk), blk(384);
+  const dim3 g((a.nstrips + RK_NS - 1) / RK_NS * a.nblk), blk(RK_NWAVES * 64);
   if (head_n > 0) {
-    if (fused) hipLaunchKernelGGL((conv_ring_kernel<1, true, 4>), g, blk, 0, st, a);
-    else hipLaunchKernelGGL((conv_ring_kernel<0, true, 5>), g, blk, 0, st, a);
+    if (fused) hipLaunchKernelGGL((conv_ring_kernel<1, true, 7>), g, blk, 0, st, a);
+    else hipLaunchKernelGGL((conv_ring_kernel<0, true, 8>), g, blk, 0, st, a);
   } else {
-    if (fused) hipLaunchKernelGGL((conv_ring_kernel<1, false, 4>), g, blk, 0, st, a);
-    else hipLaunchKernelGGL((conv_ring_kernel<0, false, 5>), g, blk, 0, st, a);
+    if (fused) hipLaunchKernelGGL((conv_ring_kernel<1, false, 7>), g, blk, 0, st, a);
+    else hipLaunchKernelGGL((conv_ring_kernel<0, false, 8>), g, blk, 0, st, a);
   }
   return lss_launch_status();
 }

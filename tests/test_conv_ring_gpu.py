@@ -55,17 +55,19 @@ def test_ring_conv_vs_torch_and_tile_kernel(ops, report, cfg, monkeypatch):
     x2g = ops.nchw_to_nhwc(x2.cuda(), 1) if C2 else None
     wr = ops.pack_conv_weight_ring(w.cuda())
     wt = ops.pack_conv_weight(w.cuda(), 1)
+    tile_ok = (Cx % 64 == 0 and C2 % 64 == 0)  # the tile kernel's K block is 64 channels
     before = ops.N.lib().lss_conv2d_ring_timeouts()
     if head_n:
         hw, hb = torch.randn(head_n, Cout, generator=gen) * Cout ** -0.5, torch.randn(head_n, generator=gen)
         ref = torch.nn.functional.conv2d(ref, hw.view(head_n, Cout, 1, 1), hb)
         out = ops.conv3x3_head_nchw(xg, wr, scale.cuda(), shift.cuda(), hw.cuda(), hb.cuda(), x2=x2g, up=up, relu=relu)
-        old = ops.conv3x3_head_nchw(xg, wt, scale.cuda(), shift.cuda(), hw.cuda(), hb.cuda(), x2=x2g, up=up, relu=relu)
+        old = ops.conv3x3_head_nchw(xg, wt, scale.cuda(), shift.cuda(), hw.cuda(), hb.cuda(), x2=x2g, up=up,
+                                    relu=relu) if tile_ok else out
         out2 = ops.conv3x3_head_nchw(xg, wr, scale.cuda(), shift.cuda(), hw.cuda(), hb.cuda(), x2=x2g, up=up, relu=relu)
         out, old, out2 = out.cpu(), old.cpu(), out2.cpu()
     else:
         y = ops.conv2d_nhwc(xg, wr, (3, 3), 1, 1, scale.cuda(), shift.cuda(), None, relu, x2g, up, None, 1)
-        y0 = ops.conv2d_nhwc(xg, wt, (3, 3), 1, 1, scale.cuda(), shift.cuda(), None, relu, x2g, up, None, 1)
+        y0 = ops.conv2d_nhwc(xg, wt, (3, 3), 1, 1, scale.cuda(), shift.cuda(), None, relu, x2g, up, None, 1) if tile_ok else y
         y2 = ops.conv2d_nhwc(xg, wr, (3, 3), 1, 1, scale.cuda(), shift.cuda(), None, relu, x2g, up, None, 1)
         out, old, out2 = ops.nhwc_to_nchw(y, 1).cpu(), ops.nhwc_to_nchw(y0, 1).cpu(), ops.nhwc_to_nchw(y2, 1).cpu()
     assert ops.N.lib().lss_conv2d_ring_timeouts() == before, "a flag wait of the ring kernel hit its bound"

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Diagnostic builds of csrc/conv_ring.hip linked against the other objects of the shipped library:
+#   diag_libs/liblss_STATS.so   (-DRK_STATS: wait statistics, tools/ring_stats.py)
+#   diag_libs/liblss_NOBLEND.so (-DRK_DIAG_NOBLEND: timing-only, the upsampled patch stays zero)
+# Use through LSS_HIP_LIB=<path>.  Run after `python -m lss2_multimodal_nu_amd.build_native`.
+set -e
+cd "$(dirname "$0")/../lss2_multimodal_nu_amd/csrc"
+mkdir -p ../../diag_libs /tmp/lss_diag
+for v in STATS NOBLEND "$@"; do
+  def=-DRK_$v; [ "$v" = NOBLEND ] && def=-DRK_DIAG_NOBLEND
+  /opt/rocm/bin/hipcc -c conv_ring.hip -o /tmp/lss_diag/conv_ring_$v.o -O3 -fPIC -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize $def
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../diag_libs/liblss_$v.so $(ls build/*.o | grep -v conv_ring.o) /tmp/lss_diag/conv_ring_$v.o -ldl
+done
+ls -la ../../diag_libs
