@@ -477,27 +477,31 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
   // keeps the MFMAs behind them (cdna_hip_programming.md section 5.4 rule 18).
   bf16x8 fw[4], fp[5];
 #define RK_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-  auto lane_now = [&]() {
-    int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(l));
-    return l;
-  };
-  auto w_addr = [&](int slot) { return L::RING + cg * 4096 + lane_now() * 16 + slot * RK_SLAB; };
-  auto p_addr = [&](int buf, auto TAPc) {
-    constexpr int TAP = decltype(TAPc)::value;
-    const int l = lane_now(), n_ = l & 15, kq_ = l >> 4;
-    int p = (((n_ >> 2) * RK_PW + (n_ & 3)) * RK_POSB + (kq_ << 4)) ^ (((n_ >> 2) & 1) << 5);
-    if (TAP / 3 == 1) p ^= 32;
-    return p + (L::PATCH + sidx * RK_STRIP_PATCH) + buf * (RK_NS * RK_STRIP_PATCH);
-  };
+  // The two lane-dependent offsets - weight fragment (cg * 4096 + lane * 16 < 8192) and pixel fragment (< 8192) - live
+  // packed in ONE register; an address is (field | or + wave-uniform part): 1-2 VALU where the first builds spent ~25
+  // per step recomputing them from the lane id.  The few VALU / SALU instructions of a step are placed BETWEEN the
+  // MFMA pairs of phase A (they issue in the shadow of the matrix pipe) instead of in one block between the phases,
+  // where neither this wave nor - when the two consumer waves of a SIMD run in step - its partner issues MFMAs.
+  const unsigned int lanepk =
+      (unsigned int)(cg * 4096 + lane * 16) |
+      ((unsigned int)((((n >> 2) * RK_PW + (n & 3)) * RK_POSB + (kq << 4)) ^ (((n >> 2) & 1) << 5)) << 16);
   const unsigned int flag_base = (unsigned int)(__UINTPTR_TYPE__)flags;
+  const int pconst = L::PATCH + sidx * RK_STRIP_PATCH;
+  // FREE counters: lane 0 adds 1 (exec narrowed inside the asm: no branch around it)
+  auto add1 = [&](int word) {
+    unsigned long long save;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save)
+                 : "v"(flag_base + 4 * word), "v"(1)
+                 : "memory");
+  };
 
   int slot = 0, gen = 1, buf = 0, pgen = 1;
   rk_wait_ge(flags + F_FULL_P + 0, RK_NPATCH);
   rk_wait_ge(flags + F_FULL_W + 0, 1);
   int fnext;  // FULL word of the next step's slot, read one step ahead
   {
-    const int wa = w_addr(0), pa = p_addr(0, std::integral_constant<int, 0>{});
+    const int wa = (int)(lanepk & 0xffffu) + L::RING, pa = (int)(lanepk >> 16) + pconst;
     RK_DSR(fw[0], wa, 0);
     RK_DSR(fw[1], wa, 1024);
     asm volatile("ds_read_b32 %0, %1" : "=v"(fnext) : "v"(flag_base + 4 * (F_FULL_W + (1 % NSL))));
@@ -512,6 +516,17 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
     constexpr int TAP = decltype(TAPc)::value;
     constexpr int NT = (TAP + 1) % 9;
     constexpr int POFF = (NT / 3) * (RK_PW * RK_POSB) + (NT % 3) * RK_POSB;  // tap offset of the next step's pixel fragments
+    {
+      const int wa = (int)(lanepk & 0xffffu) + (L::RING + slot * RK_SLAB);
+      RK_DSR(fw[2], wa, 2048);
+      RK_DSR(fw[3], wa, 3072);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // phase A; the next step's bookkeeping and addresses ride between its MFMA pairs
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fw[0]), "+v"(fw[1]), "+v"(fp[0]));
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0], fp[0], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1], fp[0], acc[0][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     int nslot = slot + 1, ngen = gen;
     if (nslot == NSL) { nslot = 0; ++ngen; }
     int nbuf = buf, npgen = pgen;
@@ -519,20 +534,15 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
       nbuf = buf ^ 1;
       if (nbuf == 0) ++npgen;
     }
-    {
-      const int wa = w_addr(slot);
-      RK_DSR(fw[2], wa, 2048);
-      RK_DSR(fw[3], wa, 3072);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // phase A
-    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fw[0]), "+v"(fw[1]), "+v"(fp[0]));
-    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0], fp[0], acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1], fp[0], acc[0][1], 0, 0, 0);
+    const int wan = (int)(lanepk & 0xffffu) + (L::RING + nslot * RK_SLAB);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fp[1]));
     acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0], fp[1], acc[1][0], 0, 0, 0);
     acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1], fp[1], acc[1][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int pan = (int)((lanepk >> 16) ^ (NT / 3 == 1 ? 32u : 0u)) + (pconst + nbuf * (RK_NS * RK_STRIP_PATCH));
+    const int n2 = nslot + 1 == NSL ? 0 : nslot + 1;
+    const unsigned int fa = flag_base + 4 * (F_FULL_W + n2);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fp[2]));
     acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0], fp[2], acc[2][0], 0, 0, 0);
@@ -546,19 +556,15 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
     acc[4][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0], fp[4], acc[4][0], 0, 0, 0);
     acc[4][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1], fp[4], acc[4][1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    int pa = 0;
     if (!last) {
       // the next step's slab (and, at the last tap, the next chunk's patch) must have been published; the FULL word
       // was read a step ago, ahead of fragments phase A has waited for
       if (__builtin_amdgcn_readfirstlane(fnext) < ngen) st0 += 1 + rk_wait_ge(flags + F_FULL_W + nslot, ngen);
       if (TAP == 8) st1 += rk_wait_ge(flags + F_FULL_P + nbuf, RK_NPATCH * npgen);
       asm volatile("" ::: "memory");
-      const int wa = w_addr(nslot);
-      RK_DSR(fw[0], wa, 0);
-      RK_DSR(fw[1], wa, 1024);
-      const int n2 = nslot + 1 == NSL ? 0 : nslot + 1;
-      asm volatile("ds_read_b32 %0, %1" : "=v"(fnext) : "v"(flag_base + 4 * (F_FULL_W + n2)));
-      pa = p_addr(nbuf, std::integral_constant<int, NT>{});
+      RK_DSR(fw[0], wan, 0);
+      RK_DSR(fw[1], wan, 1024);
+      asm volatile("ds_read_b32 %0, %1" : "=v"(fnext) : "v"(fa));
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fw[2]), "+v"(fw[3]));
     } else {
@@ -568,30 +574,30 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
     acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[2], fp[0], acc[0][2], 0, 0, 0);
     acc[0][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[3], fp[0], acc[0][3], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    rk_add1(flags + F_FREE_W + slot, lane);  // the wave has waited for fragments 2, 3: every read of this slab is done
-    if (!last) RK_DSR(fp[0], pa, POFF + 0 * 4 * RK_POSB);
+    add1(F_FREE_W + slot);  // the wave has waited for fragments 2, 3: every read of this slab is done
+    if (!last) RK_DSR(fp[0], pan, POFF + 0 * 4 * RK_POSB);
     __builtin_amdgcn_sched_barrier(0);
     acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[2], fp[1], acc[1][2], 0, 0, 0);
     acc[1][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[3], fp[1], acc[1][3], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (!last) RK_DSR(fp[1], pa, POFF + 1 * 4 * RK_POSB);
+    if (!last) RK_DSR(fp[1], pan, POFF + 1 * 4 * RK_POSB);
     __builtin_amdgcn_sched_barrier(0);
     acc[2][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[2], fp[2], acc[2][2], 0, 0, 0);
     acc[2][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[3], fp[2], acc[2][3], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (!last) RK_DSR(fp[2], pa, POFF + 2 * 4 * RK_POSB);
+    if (!last) RK_DSR(fp[2], pan, POFF + 2 * 4 * RK_POSB);
     __builtin_amdgcn_sched_barrier(0);
     acc[3][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[2], fp[3], acc[3][2], 0, 0, 0);
     acc[3][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[3], fp[3], acc[3][3], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (!last) RK_DSR(fp[3], pa, POFF + 3 * 4 * RK_POSB);
+    if (!last) RK_DSR(fp[3], pan, POFF + 3 * 4 * RK_POSB);
     __builtin_amdgcn_sched_barrier(0);
     acc[4][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[2], fp[4], acc[4][2], 0, 0, 0);
     acc[4][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[3], fp[4], acc[4][3], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (!last) RK_DSR(fp[4], pa, POFF + 4 * 4 * RK_POSB);
+    if (!last) RK_DSR(fp[4], pan, POFF + 4 * 4 * RK_POSB);
     // behind the last block every pixel fragment of this chunk has arrived (phase A waited for them)
-    if (TAP == 8) rk_add1(flags + F_FREE_P + buf, lane);
+    if (TAP == 8) add1(F_FREE_P + buf);
     __builtin_amdgcn_sched_barrier(0);
     slot = nslot; gen = ngen; buf = nbuf; pgen = npgen;
   };
