@@ -305,8 +305,11 @@ def main():
     dom_flops = 2.0 * B * X * Y * 128 * (256 * 9 + 4)   # 3x3 256 -> 128 on the upsampled grid + the 1x1 head (4 classes)
     dom_us = ms_dom * 1e3 / n_dom if n_dom else 0.0
     dom_tf = dom_flops / (dom_us * 1e-6) / 1e12 if dom_us else 0.0
-    dom_traffic = pmc_traffic("conv_lds_kernel<2, 128, 1, 3, 3, 1, 32, 1, true")
-    dominant = {"kernel": "conv_lds_kernel<2,128,1,3,3,1,32,1,HEAD> = BevEncode.up2: x2 bilinear upsample (fused gather) + 3x3 "
+    ring = os.environ.get("LSS_CONV_RING") != "0" and args.precision == "bf16"
+    dom_name = "conv_ring_kernel<1, true" if ring else "conv_lds_kernel<2, 128, 1, 3, 3, 1, 32, 1, true"
+    dom_traffic = pmc_traffic(dom_name)
+    dominant = {"kernel": ("conv_ring_kernel<MODE 1, HEAD> (loader / consumer ring kernel, csrc/conv_ring.hip)" if ring else
+                           "conv_lds_kernel<2,128,1,3,3,1,32,1,HEAD>") + " = BevEncode.up2: x2 bilinear upsample (fused gather) + 3x3 "
                           "conv 256->128 + BN + ReLU + 1x1 head, one launch; own HIP-event bracket in a separate pass of the "
                           "same K steps (outside the timed region)",
                 "bound": "mfma", "flops_per_launch": dom_flops, "avg_us": dom_us, "launches": n_dom, "achieved": dom_tf,
@@ -329,7 +332,8 @@ def main():
                                          "-> BevEncode -> 400x400x4" % B}[args.workload],
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d (sample-sharded, no collective)" % world,
                    "precision": args.precision, "spinup_ms": args.spinup_ms, "calibration": "CPU tensors per step; 3x3 inverses on host (exact-index contract), 576 floats passed in the kernel arguments (no H2D copy)"},
-        "roofline": {"kernel": "conv_lds_kernel: the 16 BevEncode launches of a step (stride-2 convs carry their 1x1 downsample, up2 its head), one HIP-event "
+        "roofline": {"kernel": "conv_lds_kernel / conv_ring_kernel: the 16 BevEncode launches of a step (stride-2 convs carry their 1x1 downsample, up2 its head; "
+                               "the three big 3x3 layers run on the ring kernel), one HIP-event "
                                "bracket around the group (per-launch brackets cost ~10 us of idle each)",
                      "bound": "mfma", "achieved": conv_tf, "peak": peak_tf, "unit": "TFLOP/s",
                      "frac": conv_tf / peak_tf, "traffic": conv_traffic[0], "traffic_unit": "HBM bytes per launch (PMC)",

@@ -158,6 +158,19 @@ __device__ __forceinline__ uint4 rk_blend(const uint4& q00, const uint4& q01, co
   return out;
 }
 
+// Wave priorities (s_setprio; -DRK_PRIO_x=n for A/B builds).  Measured on MI355X, three big convs, same box:
+// consumers 0 / patch loaders 3 / weight loader 2: 211.0 us; 2 / 0 / 3: 220.5; 0 / 0 / 0: 220.6; 1 / 0 / 3: 220.1 -
+// the blend has to be served promptly (the consumers wait for the patch at every chunk boundary), the MFMAs find
+// their slots anyway.
+#ifndef RK_PRIO_C
+#define RK_PRIO_C 0
+#endif
+#ifndef RK_PRIO_P
+#define RK_PRIO_P 3
+#endif
+#ifndef RK_PRIO_W
+#define RK_PRIO_W 2
+#endif
 constexpr int RK_NS = 4;              // strips per workgroup
 constexpr int RK_NCONS = 2 * RK_NS;   // consumer waves: (strip, 64-channel half)
 constexpr int RK_NPATCH = 3;          // patch-loader waves
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
 
   if (wave == RK_NCONS) {
     // =============================== weight loader ===============================
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(RK_PRIO_W);
     const unsigned char* wsrc = a.w + (size_t)T.nb * a.nch * 9 * RK_SLAB + lane * 16;
     // Policy: issue a slab whenever its slot is free (at most LA + 1 in flight); while the next slot is NOT free, wait
     // for the OLDEST slab in flight only (a counted vmcnt: the wave blocks for what is left of that slab's latency,
@@ -271,8 +284,10 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
         asm volatile("" ::: "memory");
       }
       unsigned char* dst = smem + L::RING + slot * RK_SLAB;
+#ifndef RK_DIAG_NOWDMA  // timing-only build: no weight traffic, the hand-off protocol alone
 #pragma unroll
       for (int k = 0; k < 8; ++k) rk_glds16(wsrc + (size_t)i * RK_SLAB + k * 1024, dst + k * 1024);
+#endif
       ++inflight;
       if (inflight > LA) publish_oldest();
       if (++slot == NSL) { slot = 0; ++gen; }
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
     // Patch loader p takes the 1-KiB pieces it = p, p + 3, ... of a patch buffer (12 of 36).  Piece it = (strip it / 9,
     // block it % 9): lane -> patch position 16 * (it % 9) + (lane >> 2), 16-B slot lane & 3, which holds channel piece
     // slot ^ ((row & 1) << 1).  FULL_P / FREE_S etc. are counters: every patch loader adds its share.
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(RK_PRIO_P);
     const int pw = wave - RK_NCONS - 1;
     constexpr int NIT = RK_NPIECE / RK_NPATCH;  // 12
     const int nskip = MODE == 1 ? a.C2 / RK_KC : a.nch;  // chunks copied straight from a full-resolution tensor
@@ -446,6 +461,7 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
   }
 
   // ================================== consumers ==================================
+  __builtin_amdgcn_s_setprio(RK_PRIO_C);
   const int sidx = wave >> 1, cg = wave & 1;
   const int n = lane & 15, kq = lane >> 4;
   // this wave's strip (selects, not indexing: a runtime-indexed struct member would live in scratch)
