@@ -21,7 +21,10 @@ messages beat one per parameter):
 
 Works with any torch.distributed backend (tests run it on gloo/CPU with world_size 2).  With
 `LSS_DP_DIRECT_RCCL=1` the collective goes through this package's own RCCL communicator and the
-C-ABI entry `lss_allreduce_bucket` (include/lss_hip.h) instead of torch's process group.
+C-ABI entry `lss_allreduce_bucket` (include/lss_hip.h) instead of torch's process group - on a
+SIDE stream fenced with events (the bucket's gradients are complete on the compute stream ->
+event -> the side stream waits, reduces, records -> `all_reduce_mean` makes the compute stream
+wait), so it overlaps the rest of backward exactly like the torch.distributed path.
 """
 import os
 
@@ -103,7 +106,7 @@ class GradBucket:
         lo, hi, _ = self.buckets[b]
         seg = self.flat[lo:hi]
         if self._direct is not None:
-            self._direct.all_reduce_sum(seg)
+            self._work.append(self._direct.all_reduce_sum_async(seg))  # side stream, event-fenced
             return
         self._work.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -155,6 +158,41 @@ class GradBucket:
         return unused
 
 
+class _StreamWork:
+    """Handle of a collective enqueued on a side stream: `wait()` orders the caller's current stream behind it."""
+
+    def __init__(self, done_event, keep):
+        self.done, self.keep = done_event, keep
+
+    def wait(self):
+        _streams().current_stream().wait_event(self.done)
+        self.keep = None
+
+
+def _streams():
+    """The stream / event provider (torch.cuda); a test substitutes a recording fake to check the fence order
+    without a GPU."""
+    return _stream_api[0]
+
+
+_stream_api = [torch.cuda]
+
+
+def _fenced_launch(comm, t):
+    """compute stream --event--> side stream: collective --event--> (wait) compute stream."""
+    api = _streams()
+    if getattr(comm, "_side", None) is None:
+        comm._side = api.Stream()
+    ready = api.Event()
+    ready.record(api.current_stream())          # the bucket's gradients are complete here
+    comm._side.wait_event(ready)
+    with api.stream(comm._side):
+        comm.all_reduce_sum(t)                  # enqueued on the side stream (N.stream() = torch's current)
+    done = api.Event()
+    done.record(comm._side)
+    return _StreamWork(done, t)
+
+
 class DirectRccl:
     """This package's own RCCL communicator over the ranks of a torch.distributed group, driven
     through the C ABI (`lss_rccl_*`, `lss_allreduce_bucket` in include/lss_hip.h).  The unique id is
@@ -170,11 +208,22 @@ class DirectRccl:
         self.comm = N.rccl_comm_init(uid[0], world, rank)
         self.world = world
 
-    def all_reduce_sum(self, t):
+    def _check(self, t):
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
             raise ValueError("all_reduce_sum: contiguous fp32 GPU tensor")
+
+    def all_reduce_sum(self, t):
+        """In-stream form: the collective is enqueued on the caller's current stream."""
+        self._check(t)
         N = self.N
         N.check(N.lib().lss_allreduce_bucket(self.comm, N.ptr(t), t.numel(), N.stream()), "lss_allreduce_bucket")
+
+    def all_reduce_sum_async(self, t):
+        """Overlapped form: everything enqueued so far on the current (compute) stream happens before the
+        collective, which runs on this communicator's own side stream; the returned work's `wait()` makes the
+        then-current stream wait for it (no host blocking anywhere)."""
+        self._check(t)
+        return _fenced_launch(self, t)
 
     def close(self):
         if self.comm is not None:

@@ -156,3 +156,88 @@ def test_bucket_views_clip_and_unused_parameters():
     torch.testing.assert_close(total, total_ref, rtol=1e-5, atol=1e-6)
     for p, rp in zip(net.parameters(), ref_params):
         torch.testing.assert_close(p.grad, rp.grad, rtol=1e-5, atol=1e-7)
+
+
+class _FakeStreams:
+    """torch.cuda stand-in that records the order of stream / event operations (no GPU needed)."""
+
+    def __init__(self):
+        self.log = []
+        self.cur = "compute"
+        outer = self
+
+        class Event:
+            n = 0
+
+            def __init__(self):
+                Event.n += 1
+                self.name = "ev%d" % Event.n
+
+            def record(self, stream):
+                outer.log.append(("record", self.name, stream if isinstance(stream, str) else stream.name))
+
+        class Stream:
+            def __init__(self):
+                self.name = "side"
+
+            def wait_event(self, ev):
+                outer.log.append(("wait", self.name, ev.name))
+
+        class _Ctx:
+            def __init__(self, st):
+                self.st = st
+
+            def __enter__(self):
+                self.prev, outer.cur = outer.cur, self.st.name
+
+            def __exit__(self, *a):
+                outer.cur = self.prev
+
+        class _Cur:
+            name = "compute"
+
+            def wait_event(self, ev):
+                outer.log.append(("wait", outer.cur, ev.name))
+
+        self.Event, self.Stream = Event, Stream
+        self.stream = lambda st: _Ctx(st)
+        self.current_stream = lambda: (_Cur() if outer.cur == "compute" else None) or outer.cur
+
+
+def test_direct_collective_runs_on_a_fenced_side_stream(monkeypatch):
+    """the direct-RCCL collective of a bucket goes to a side stream behind an event recorded on
+    the compute stream (so it overlaps the rest of backward), and `all_reduce_mean` makes the compute stream wait
+    for the side stream's completion event - checked on the recorded operation order, no GPU."""
+    fake = _FakeStreams()
+    monkeypatch.setattr(dp, "_stream_api", [fake])
+
+    class Comm:  # DirectRccl without RCCL: the same async entry, the collective itself only logged
+        _side = None
+
+        def all_reduce_sum(self, t):
+            fake.log.append(("allreduce", fake.cur, int(t.numel())))
+
+        def all_reduce_sum_async(self, t):
+            return dp._fenced_launch(self, t)
+
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 8))
+    bucket = dp.GradBucket(lin.parameters(), n_buckets=2)
+    bucket.use_direct_rccl(Comm())
+    monkeypatch.setattr(bucket, "_world", lambda: 2)
+    bucket.zero()
+    lin(torch.randn(3, 8)).sum().backward()          # hooks launch the buckets from inside backward
+    launched_in_backward = [e for e in fake.log if e[0] == "allreduce"]
+    assert len(launched_in_backward) == len(bucket.buckets) == 2
+    assert all(e[1] == "side" for e in launched_in_backward)          # never on the compute stream
+    bucket.all_reduce_mean()
+    # per bucket: record(ready, compute) -> side waits(ready) -> allreduce on side -> record(done, side); then the
+    # compute stream waits for every done event
+    ops_ = [e[0] for e in fake.log]
+    assert ops_[:4] == ["record", "wait", "allreduce", "record"] and ops_[4:8] == ["record", "wait", "allreduce", "record"]
+    for k in (0, 4):
+        rec, wait, ar, done = fake.log[k:k + 4]
+        assert rec[2] == "compute" and wait == ("wait", "side", rec[1]) and ar[1] == "side" and done[2] == "side"
+    waits = fake.log[8:]
+    assert [w[:2] for w in waits] == [("wait", "compute")] * 2
+    assert {w[2] for w in waits} == {fake.log[3][1], fake.log[7][1]}
