@@ -428,6 +428,11 @@ int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_packed, con
                         int B, int H, int W, int Cx, int C2, int up, int Cout, int head_n,
                         int relu, void* stream);
 
+/* 1 when lss_lift_splat_forward (f32 depthnet math) runs (B,N,D,fH,fW,C | X,Y,Z) on the region-bucketed pipeline
+ * (K2 || K3 with LDS region histograms -> region fill -> fixed-point region splat), 0 when the problem exceeds its
+ * limits and the voxel-list pipeline (K3, K4, K2, K5) is used.  Honours LSS_SPLAT_LEGACY. */
+int lss_region_pipeline_ok(int B, int N, int D, int fH, int fW, int C, int X, int Y, int Z);
+
 /* ---------------------------------------------------------------------------
  * Host-overhead reducers: the same kernels, several launches per call.  A caller
  * that binds these issues ONE FFI call for the whole lift-splat level and ONE for

@@ -30,8 +30,6 @@ int lss_conv_ring_launch(const void* x, const void* x2, const void* w_ring, cons
 
 namespace {
 
-constexpr bool NT_OK(int kh, int kw) { return kh * kw >= 6; }
-
 struct ConvArgs {
   const void* x;
   const void* x2;
@@ -62,7 +60,6 @@ struct ConvArgs {
   const float* head_b;
   float* head_out;
   int head_n;
-  int head_valu;  // A/B switch: the fused head's VALU / DPP form instead of the MFMA form
   // diagnostics (tools/conv_phase_stamps.py): 8 x 100-MHz s_memrealtime stamps per workgroup, or null
   unsigned long long* stamps;
   int src_lds;  // MODE 1, KC = 32: the low-res source patch of a chunk is staged in LDS (see SRC below)
@@ -346,33 +343,27 @@ __device__ __forceinline__ void wait_vmcnt() {
 // HEAD: the epilogue reduces the fused 1x1 head instead of storing the activation (its own instantiation: the
 // head and the store path each keep only their own operands live - the store path's residual prefetch and
 // the head's operand fragments together overflowed the 168-register budget of the KC = 32 kernels).
-// PFB (fused upsample, KC = 32): the bilinear blend of the NEXT chunk's patch is computed into registers while the
-// last four taps of the current chunk run (its VALU work overlaps their MFMAs), so the chunk boundary is a barrier
-// and three LDS stores instead of a synchronous blend phase that every resident workgroup hits in lockstep.  Costs
-// the third workgroup per CU: the blended pieces and their temporaries do not fit the 168-register budget - and that
-// turned out to cost more than the hidden blend returns (see conv_pfb_on): kept as a switchable variant.
+// (Variants built, measured and removed in round 3 - numbers in DESIGN.md section 4: PFB = blend of the next chunk
+// under the last taps' MFMAs, PSP = pixel-split pairs on one weight ring, 64-channel tall tiles, mixed full / half
+// height launches, s_setprio around the MFMA groups, a 3-slot ring for KC = 32.  The big layers now run on the
+// loader / consumer kernel of conv_ring.hip at the sizes it takes; this kernel keeps them at small batch.)
 // LDS bytes of one workgroup of the tile body below (same formulas; the body static_asserts the match)
-#ifndef LSS_CONV_RING32
-#define LSS_CONV_RING32 4  // ring slots of the KC = 32 kernels (-DLSS_CONV_RING32=3: the round-1 depth, for A/B builds)
-#endif
-template <int RT, int BN, int MODE, int KH, int KW, int KC, int KSP, int PSP = 1, int TPS = 1>
+constexpr int LSS_CONV_RING32 = 4;  // ring slots of the KC = 32 kernels
+template <int RT, int BN, int MODE, int KH, int KW, int KC, int KSP, int TPS = 1>
 constexpr int conv_lds_smem_bytes() {
   constexpr int TH = (4 / (BN / 64)) * RT * 2, IW = 16 + KW - 1, IH = TH + KH - 1, POSB = KC * 2 + 16;
   constexpr int IROWB = (IW * POSB + 255) / 256 * 256, W_BYTES = TPS * BN * KC * 2, PPP = KC / 8;
-  constexpr int OUT_BYTES = PSP * (TH / (KC == 32 ? 2 : 1)) * 16 * (BN + 4) * 4;
-  constexpr int GROUP_BYTES = ((KC == 32 ? LSS_CONV_RING32 : 3) * W_BYTES + PSP * IH * IROWB + 1023) / 1024 * 1024;
+  constexpr int OUT_BYTES = (TH / (KC == 32 ? 2 : 1)) * 16 * (BN + 4) * 4;
+  constexpr int GROUP_BYTES = ((KC == 32 ? LSS_CONV_RING32 : 3) * W_BYTES + IH * IROWB + 1023) / 1024 * 1024;
   constexpr int SRC_PIECES = (MODE == 1 && KC == 32) ? (((IH - 1) / 2 + 3) * ((IW - 1) / 2 + 3) * PPP + 63) / 64 : 0;
-  return (KSP * GROUP_BYTES > OUT_BYTES ? KSP * GROUP_BYTES : OUT_BYTES) + PSP * SRC_PIECES * 1024;
+  return (KSP * GROUP_BYTES > OUT_BYTES ? KSP * GROUP_BYTES : OUT_BYTES) + SRC_PIECES * 1024;
 }
 
 // The tile body: one workgroup's output tile.  bid / nwg: index of the tile in its class and the size of the class
-// (XCD-aware order), nblk_y: index of the BN-wide channel block, oy_base: first image row of the class (the mixed
-// launch below covers the top rows of every image with RT = 2 tiles and the rest with RT = 1 tiles).
-template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64, int KSP = 1, bool HEAD = false,
-          bool PFB = false, int PSP = 1, int TPS = 1>
+// (XCD-aware order), nblk_y: index of the BN-wide channel block, oy_base: first image row of the class (0).
+template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64, int KSP = 1, bool HEAD = false, int TPS = 1>
 __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int tilesY, int bid, int nwg, int nblk_y,
                                               int oy_base, unsigned char* smem) {
-  static_assert(!PFB || (MODE == 1 && KC == 32 && NT_OK(KH, KW)), "PFB is the fused-upsample, 32-channel-step variant");
   // KSP = 2: intra-workgroup split-K for grids that cannot fill the chip (layer2/layer3: 112-208
   // workgroups of 18-36 latency-bound steps on 256 CUs).  512 threads = two 4-wave groups, each
   // with its own weight ring and patch, each taking half of the input-channel chunks; the second
@@ -380,16 +371,10 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   // the main loop at the same workgroup count; barriers stay workgroup-wide (both groups run the
   // same step sequence).
   static_assert(KSP == 1 || (KSP == 2 && KC == 64), "KSP");
-  // PSP = 2 (512 threads): two 4-wave groups compute two vertically adjacent TH x 16 pixel tiles against ONE weight
-  // ring - each group has its own patch and accumulators, the eight waves share the slab DMA (half the pieces each).
-  // Halves the weight bytes streamed into LDS per MFMA: timing-only builds without the weight DMA ran the big
-  // layers 20-31 % faster (up1.conv3 65 -> 45 us), i.e. the DMA stream, not the MFMA issue, is what the 2 x 4-wave
-  // configuration pays for.  One such workgroup per CU (same 8 waves as two plain ones).
-  static_assert(PSP == 1 || (PSP == 2 && KSP == 1 && BN == 128), "PSP");
   // TPS = taps per step.  2: a step is TWO taps against a double slab - half the steps (barrier + counted wait + slot
   // hand-over each) per chunk.  For the 7x7 / 2 stem, whose 64 steps carry only 8 MFMAs per wave each: phase stamps put
   // a step at 0.43 us against 0.13 us of MFMA issue.  Needs an even tap count and the 24 KB more LDS (BN = 64 only).
-  static_assert(TPS == 1 || (TPS == 2 && (KH * KW) % 2 == 0 && KSP == 1 && PSP == 1 && MODE != 1 && !PFB), "TPS");
+  static_assert(TPS == 1 || (TPS == 2 && (KH * KW) % 2 == 0 && KSP == 1 && MODE != 1), "TPS");
   // KC = input channels per (chunk, tap) step.  64: the default.  32: half-depth slabs and patch
   // (39 KB of LDS, <= 168 VGPRs) so THREE workgroups share a CU - used for the big stride-1 layers,
   // whose 728 / 1300 tiles then run in one / two full rounds instead of 1.4 / 2.5 on 512 slots.
@@ -406,8 +391,8 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   constexpr int IN_BYTES = IH * IROWB;
   constexpr int W1_BYTES = BN * KC * 2;      // slab of one tap
   constexpr int W_BYTES = TPS * W1_BYTES;    // slab of one step
-  constexpr int WPT = W_BYTES / 4096 / PSP;  // LDS-DMA instructions per wave per step (1 KiB each)
-  constexpr int NWV = 4 * PSP;                // waves that share one slab
+  constexpr int WPT = W_BYTES / 4096;  // LDS-DMA instructions per wave per step (1 KiB each)
+  constexpr int NWV = 4;               // waves that share one slab
   constexpr int WCOLS = BN / 64;  // waves along the channel axis
   constexpr int IPT = (IH * IW * PPP + 255) / 256;  // 16-B patch pieces per thread per chunk
   constexpr int OLD = BN + 4;  // fp32 row stride of the epilogue's staged output tile
@@ -418,7 +403,7 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   // workgroups per CU) keep 4 slots = three steps ahead: a timing build that re-read one L1-hot slab ran them 9-13 %
   // faster while the KC = 64 kernel did not move, i.e. their shorter steps exposed the L2 round trip of the slab.
   constexpr int NSL = KC == 32 ? LSS_CONV_RING32 : 3, LA = NSL - 1;
-  constexpr int GROUP_BYTES = (NSL * W_BYTES + PSP * IN_BYTES + 1023) / 1024 * 1024;  // ring + patch(es) of one K-split group
+  constexpr int GROUP_BYTES = (NSL * W_BYTES + IN_BYTES + 1023) / 1024 * 1024;  // ring + patch of one K-split group
   // SRC (fused upsample, KC = 32): the low-res pixels a chunk's patch is interpolated from - at most
   // SRC_H x SRC_W source positions for scale factors >= 2 - are copied ONCE per chunk into LDS by
   // LDS-DMA while the previous chunk's taps run, and the 4-corner blend then reads LDS: 2 DMA
@@ -429,20 +414,16 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   constexpr int SRC_PIECES = SRC ? (SRC_H * SRC_W * PPP + 63) / 64 : 0;  // 1-KiB DMA pieces per chunk (5)
   constexpr int SRC_DMA = (SRC_PIECES + 3) / 4;  // DMA instructions per chunk of the wave that issues most (wave 0)
   constexpr int SRC_BYTES = SRC_PIECES * 1024;
-  constexpr int MAIN_BYTES = KSP * GROUP_BYTES > PSP * OUT_BYTES ? KSP * GROUP_BYTES : PSP * OUT_BYTES;
-  constexpr int SMEM_BYTES = MAIN_BYTES + PSP * SRC_BYTES;
-  static_assert(SMEM_BYTES <= (KSP * PSP == 2 ? 160 : (KC == 32 ? 53 : 80)) * 1024, "workgroups per CU vs 160 KiB of LDS");
+  constexpr int MAIN_BYTES = KSP * GROUP_BYTES > OUT_BYTES ? KSP * GROUP_BYTES : OUT_BYTES;
+  constexpr int SMEM_BYTES = MAIN_BYTES + SRC_BYTES;
+  static_assert(SMEM_BYTES <= (KSP == 2 ? 160 : (KC == 32 ? 53 : 80)) * 1024, "workgroups per CU vs 160 KiB of LDS");
   static_assert(!SRC || NS > LA, "the source copies retire at step LA");
-  // (A 16-row tile for the fused x2 conv - RT = 4: a wave owns 4 x 2 MFMA tiles, half the DMA pieces and 3/4 of the LDS
-  // fragment reads per MFMA, epilogue in four passes - was built and measured in round 2: 256 registers with spills, two
-  // workgroups per CU instead of three, up2 + head 123.5 -> 132.0 us on the same box.  Not kept.)
   static_assert(KC == 64 || (RT == 2 && BN == 128 && MODE != 2), "KC = 32 is built for the RT = 2, BN = 128 stride-1 tiles");
-  static_assert(SMEM_BYTES == conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP, PSP, TPS>(), "conv_lds_smem_bytes out of sync");
+  static_assert(SMEM_BYTES == conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP, TPS>(), "conv_lds_smem_bytes out of sync");
   const int grp = KSP == 2 ? (int)(threadIdx.x >> 8) : 0;  // K-split group of this wave
-  const int pgr = PSP == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;  // pixel group of this wave
   unsigned char* w_tile = smem + grp * GROUP_BYTES;
-  unsigned char* in_tile = w_tile + NSL * W_BYTES + pgr * IN_BYTES;
-  unsigned char* src_tile = smem + MAIN_BYTES + pgr * SRC_BYTES;  // SRC only
+  unsigned char* in_tile = w_tile + NSL * W_BYTES;
+  unsigned char* src_tile = smem + MAIN_BYTES;  // SRC only
 
   const int tid = threadIdx.x & 255, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -459,8 +440,8 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   const int tx = t % tilesX; t /= tilesX;
   const int ty = t % tilesY;
   const int b = t / tilesY;
-  const int oy0 = oy_base + (ty * PSP + pgr) * TH, ox0 = tx * TW, n0 = nblk_y * BN;
-  const int dwave = wave + 4 * pgr;  // index among the waves that share the weight ring
+  const int oy0 = oy_base + ty * TH, ox0 = tx * TW, n0 = nblk_y * BN;
+  const int dwave = wave;  // index among the waves that share the weight ring
   const int wc = wave % WCOLS, wr = wave / WCOLS;
   const int prow0 = wr * (2 * RT);
   auto stamp = [&](int k) {
@@ -596,26 +577,6 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
       *reinterpret_cast<uint4*>(in_tile + py * IROWB + px * POSB + part * 16) = v;
     }
   };
-  // PFB: the same blend for an upsampled chunk whose source pixels sit in src_tile, into ireg[] (fully unrolled:
-  // the pieces must stay in registers until store_in() writes them at the chunk boundary)
-  auto blend_to_regs = [&]() {
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (g_off[i] & 4) {
-        const unsigned char* p00 = src_tile + (g_off[i] & ~15);
-        const int dx = (g_off[i] & 1) ? PPP * 16 : 0, dy = (g_off[i] & 2) ? SRC_W * PPP * 16 : 0;
-        const uint4 q00 = *reinterpret_cast<const uint4*>(p00);
-        const uint4 q01 = *reinterpret_cast<const uint4*>(p00 + dx);
-        const uint4 q10 = *reinterpret_cast<const uint4*>(p00 + dy);
-        const uint4 q11 = *reinterpret_cast<const uint4*>(p00 + dy + dx);
-        v = blend_bf16x8(q00, q01, q10, q11, (float)(g_w[i] & 0xffff) * (1.f / 65536.f),
-                         (float)(g_w[i] >> 16) * (1.f / 65536.f));
-      }
-      ireg[i] = v;
-    }
-  };
-
   // SRC: source pixels of `chunk` -> src_tile (lane l of DMA block k lands at byte k*1024 + l*16)
   auto issue_src = [&](int chunk) {
     const unsigned short* xp = reinterpret_cast<const unsigned short*>(a.x);
@@ -685,26 +646,8 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
     const int row = KC == 64 ? rblk * 8 + (lane >> 3) : rblk * 16 + (lane >> 2);
     const int part = KC == 64 ? (lane & 7) ^ ((row >> 1) & 7) : (lane & 3) ^ ((row >> 2) & 3);
     const int co = min(n0 + row, a.Cout - 1);
-#if defined(LSS_CONV_DIAG_NOW)
-    // timing-only build: no weight traffic at all (results are garbage)
-#elif defined(LSS_CONV_DIAG_WQUARTER)
-    // timing-only build: a quarter of the pieces (the first of each wave's WPT)
-    if (i == 0)
-      glds16(wg + ((size_t)tap * a.Cout + co) * a.Cin + (cbase + chunk) * KC + part * 8,
-             w_tile + slot * W_BYTES + blk * 1024);
-#elif defined(LSS_CONV_DIAG_WVGPR)
-    // timing-only build: the same 16 B per lane fetched into a register instead of LDS (no LDS write, same requests)
-    {
-      const uint4 v = *reinterpret_cast<const uint4*>(wg + ((size_t)tap * a.Cout + co) * a.Cin + (cbase + chunk) * KC + part * 8);
-      asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-    }
-#elif defined(LSS_CONV_DIAG_WSAME)
-    // timing-only build: every step re-reads the slab of (tap 0, chunk 0) - same issue count, L1/L2-hot source
-    glds16(wg + ((size_t)0 * a.Cout + co) * a.Cin + part * 8, w_tile + slot * W_BYTES + blk * 1024);
-#else
     glds16(wg + ((size_t)tap * a.Cout + co) * a.Cin + (cbase + chunk) * KC + part * 8,
            w_tile + slot * W_BYTES + blk * 1024);
-#endif
   };
 
   // per-lane epilogue constants, fetched now so their latency is long gone by the epilogue
@@ -777,32 +720,20 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
         // keep the prefetch reads AHEAD of this k-step's MFMAs (hipcc's scheduler would
         // otherwise sink them next to their use and expose the LDS latency again)
         __builtin_amdgcn_sched_barrier(0);
-#ifdef LSS_CONV_SETPRIO
-        // experiment (cdna_hip_programming.md T5, -DLSS_CONV_SETPRIO): matrix work first among the SIMD's waves.
-        // Measured r02, same box: 0.5263 -> 0.5321 ms/step (-1.1 %): off.
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
           acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][0], acc[i][0], 0, 0, 0);
           acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][1], acc[i][1], 0, 0, 0);
         }
-#ifdef LSS_CONV_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         if (more && ks < WPT) issue_w1(t2, c2, slot2, ks);
       }
       // after this step's weight pieces, so that (like them) the copies have two steps to land: the
       // counted waits of step 0 and step 1 leave them in flight, the wait of step 2 retires them
       if (SRC && st == 0 && srcq) issue_src(chunk + 1);
       if (prefetch) gather_in(chunk + 1, false);  // next patch -> registers
-      // PFB: the next chunk's source pixels landed with the wait of step 2 (see below): blend them into registers now,
-      // under the MFMAs of the remaining taps
-      if (PFB && st == PF_ST && srcq) blend_to_regs();
       if (st == NS - 1 && !last_chunk) {
         lds_barrier();  // every wave is done with this chunk's patch
-        if (PFB && srcq) store_in();
-        else if (FUSED) gather_fused(chunk + 1);
+        if (FUSED) gather_fused(chunk + 1);
         else store_in();
       }
       // W(step+1) must have landed in every wave's share before anyone reads it; only the
@@ -828,7 +759,7 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   // Instead: scale/shift in registers -> fp32 tile in LDS (the ring + patch area is
   // free now) -> every thread picks up 8 consecutive channels of a pixel, adds the
   // residual (one 16-B load), ReLU, rounds to bf16 once, and stores 16 B.
-  float* otile = reinterpret_cast<float*>(smem + pgr * OUT_BYTES);
+  float* otile = reinterpret_cast<float*>(smem);
   stamp(2);
   // (the loop's final lds_barrier already guarantees every wave is done reading LDS)
   if (KSP == 2) {
@@ -950,7 +881,7 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
     if (half == 0) stamp(3);
     if (grp != 0) {
       // second K-split group: its sums were handed over above; it only keeps the barriers company
-    } else if (HEAD && a.head_n <= 16 && !a.head_valu) {
+    } else if (HEAD && a.head_n <= 16) {
       // Fused 1x1 head ON THE MATRIX PIPE (ref src/modules.py:115, up2[4]): per image row of the staged tile one
       // 16 x 16 x BN product  out[pixel][k] = sum_c relu(act[pixel][c]) * head_w[k][c]  on v_mfma_f32_16x16x32_bf16.
       // Both operands are split into bf16 hi + lo parts (x = hi + lo to 16 significant bits) and the three
@@ -1012,7 +943,7 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
         }
       }
     } else if (HEAD) {
-      // fused 1x1 head, VALU form (more than 16 classes, or LSS_CONV_HEAD_VALU=1 for A/B): the CG = BN / 8 lanes
+      // fused 1x1 head, VALU form (more than 16 classes): the CG = BN / 8 lanes
       // that hold the channels of one pixel reduce their partial dot products with DPP row operations; the
       // activation itself is never stored
       {
@@ -1113,33 +1044,11 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   }
 }
 
-template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64, int KSP = 1, bool HEAD = false,
-          bool PFB = false, int PSP = 1, int TPS = 1>
-__global__ __launch_bounds__(256 * KSP * PSP, KSP * PSP == 2 ? 1 : ((KC == 32 && !PFB) ? 3 : 2)) void conv_lds_kernel(
-    ConvArgs a, int tilesX, int tilesY) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP, PSP, TPS>()];
-  conv_lds_tile<RT, BN, MODE, KH, KW, PAD, KC, KSP, HEAD, PFB, PSP, TPS>(a, tilesX, tilesY, blockIdx.x, gridDim.x,
-                                                                        blockIdx.y, 0, smem);
-}
-
-// Mixed launch for grids that end in a partial round: the first `nfull` workgroups of every channel block are
-// full-height (RT = 2) tiles over image rows [0, oy_split) - exactly whole rounds of the 2 x 256 resident slots -
-// and the rest are half-height (RT = 1) tiles over rows [oy_split, Ho).  The tail then keeps every CU busy with
-// small tiles instead of leaving most of them one big tile short (up1.conv3: 728 tiles on 512 slots = one full
-// round and a 42 %-full one).  1-D grid, full tiles first, so the dispatcher hands the small ones out last.
-template <int BN, int MODE, int KH, int KW, int PAD, int KC, bool HEAD>
-__global__ __launch_bounds__(256, 2) void conv_lds_mixed_kernel(ConvArgs a, int tilesX, int tilesY2, int tilesY1,
-                                                                int nfull, int nhalf, int nblk, int oy_split) {
-  constexpr int B2 = conv_lds_smem_bytes<2, BN, MODE, KH, KW, KC, 1>(), B1 = conv_lds_smem_bytes<1, BN, MODE, KH, KW, KC, 1>();
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[B2 > B1 ? B2 : B1];
-  const int id = blockIdx.x;
-  if (id < nfull * nblk) {
-    conv_lds_tile<2, BN, MODE, KH, KW, PAD, KC, 1, HEAD, false>(a, tilesX, tilesY2, id % nfull, nfull, id / nfull, 0, smem);
-  } else {
-    const int k = id - nfull * nblk;
-    conv_lds_tile<1, BN, MODE, KH, KW, PAD, KC, 1, HEAD, false>(a, tilesX, tilesY1, k % nhalf, nhalf, k / nhalf, oy_split,
-                                                               smem);
-  }
+template <int RT, int BN, int MODE, int KH, int KW, int PAD, int KC = 64, int KSP = 1, bool HEAD = false, int TPS = 1>
+__global__ __launch_bounds__(256 * KSP, KSP == 2 ? 1 : (KC == 32 ? 3 : 2)) void conv_lds_kernel(ConvArgs a, int tilesX,
+                                                                                                  int tilesY) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[conv_lds_smem_bytes<RT, BN, MODE, KH, KW, KC, KSP, TPS>()];
+  conv_lds_tile<RT, BN, MODE, KH, KW, PAD, KC, KSP, HEAD, TPS>(a, tilesX, tilesY, blockIdx.x, gridDim.x, blockIdx.y, 0, smem);
 }
 
 // OIHW fp32 -> [tap][co][ci] in T
@@ -1192,22 +1101,13 @@ inline int conv_src_lds_ok(const ConvArgs& a) {
   return a.up >= 2 && a.ry * 9.f < 4.99f && a.rx * 17.f < 8.99f;
 }
 
-// LSS_CONV_PFB=1 selects the prefetched-blend variant (PFB) of the fused-upsample convs.  Off by default: measured
-// on MI355X (r02, same box A/B) it LOSES - up2.1 126.7 -> 131.9 us, up1.conv0 80.8 -> 87.3 us, step 0.516 -> 0.528 ms:
-// hiding the blend under the MFMAs is worth less than the third co-resident workgroup it costs (226 VGPRs).
-inline bool conv_pfb_on() {
-  const char* e = getenv("LSS_CONV_PFB");
-  return e != nullptr && atoi(e) != 0;
-}
-
 // Tile selection + launch of conv_lds_kernel.  BN = 64 for narrow layers, else 128; RT = 2
 // (throughput shape) unless that grid would leave the 256 CUs under-filled, in which case
 // half-height workgroups (RT = 1) shorten the per-workgroup critical path instead.
 template <int MODE, int KH, int KW, int PAD>
 void launch_conv_lds(const ConvArgs& a, hipStream_t st) {
   const int tilesX = lss_cdiv(a.Wo, 16);
-  bool narrow = a.Cout <= 64;
-  if (const char* e = getenv("LSS_CONV_BN64")) narrow = narrow || (atoi(e) != 0 && MODE == 0 && a.Cout % 64 == 0);
+  const bool narrow = a.Cout <= 64;
   const int th2 = narrow ? 16 : 8;
   const int nblk = lss_cdiv(a.Cout, narrow ? 64 : 128);
   const long long nwg2 = (long long)tilesX * lss_cdiv(a.Ho, th2) * a.B * nblk;
@@ -1223,8 +1123,8 @@ void launch_conv_lds(const ConvArgs& a, hipStream_t st) {
         // the 7x7 / 2 stem: two taps per step (LSS_CONV_TPS=1 = one, for A/B)
         static const bool tps2 = getenv("LSS_CONV_TPS") == nullptr || atoi(getenv("LSS_CONV_TPS")) != 1;
         if (tps2) {
-          hipLaunchKernelGGL((conv_lds_kernel<1, 64, MODE, KH, KW, PAD, 64, 1, false, false, 1, 2>), g, dim3(256), 0, st, a,
-                             tilesX, tilesY);
+          hipLaunchKernelGGL((conv_lds_kernel<1, 64, MODE, KH, KW, PAD, 64, 1, false, 2>), g, dim3(256), 0, st, a, tilesX,
+                             tilesY);
           return;
         }
       }
@@ -1243,53 +1143,7 @@ void launch_conv_lds(const ConvArgs& a, hipStream_t st) {
         if (kc32) {
           ConvArgs a32 = a;
           a32.src_lds = MODE == 1 ? conv_src_lds_ok(a) : 0;
-          if constexpr (MODE == 1) {
-            if (a32.src_lds && conv_pfb_on()) {
-              hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD, 32, 1, false, true>), g, dim3(256), 0, st, a32,
-                                 tilesX, tilesY);
-              return;
-            }
-          }
           hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD, 32>), g, dim3(256), 0, st, a32, tilesX, tilesY);
-          return;
-        }
-      }
-      // LSS_CONV_MIXED=1: a grid that ends in a partial round of the 512 resident slots (2 per CU) gets a mixed launch:
-      // whole rounds of full-height tiles over the top rows of every image, half-height tiles over the rest.  Off by
-      // default - measured on MI355X (r02): up1.conv3 (728 tiles) 64.1 -> 68.8 us stand-alone, 0.5106 -> 0.5111 ms end
-      // to end: the half-height tiles are ~1.6x less efficient per FLOP (weight DMA + barrier per 8 MFMAs), which eats
-      // what the fuller tail returns.  Bitwise the plain launch's result (test_k8_mixed_tile_launch).
-      if constexpr (MODE == 0 && KH == 3) {
-        const long long slots = 512, per_band = (long long)tilesX * a.B * nblk;  // workgroups per full row band
-        const long long rounds = nwg2 / slots, rest = nwg2 - rounds * slots;
-        bool mixed = rounds >= 1 && rest * 10 >= slots && rest * 10 <= slots * 8 && per_band <= slots;
-        const char* emx = getenv("LSS_CONV_MIXED");
-        mixed = mixed && emx != nullptr && atoi(emx) != 0;
-        if (mixed) {
-          const int kf = (int)(rounds * slots / per_band);       // full row bands per image
-          const int oy_split = kf * th2;
-          if (kf >= 1 && oy_split < a.Ho) {
-            const int tilesY1 = lss_cdiv(a.Ho - oy_split, th2 / 2);
-            const int nfull = tilesX * kf * a.B, nhalf = tilesX * tilesY1 * a.B;
-            hipLaunchKernelGGL((conv_lds_mixed_kernel<128, MODE, KH, KW, PAD, 64, false>), dim3((nfull + nhalf) * nblk),
-                               dim3(256), 0, st, a, tilesX, kf, tilesY1, nfull, nhalf, nblk, oy_split);
-            return;
-          }
-        }
-      }
-      // Pixel-split pairs (PSP = 2): one 512-thread workgroup = two stacked 8 x 16 tiles on one weight ring.
-      if constexpr (MODE == 0 && KH == 3) {
-        // Off by default - measured on MI355X (r02, same box): up1.conv3 64.6 -> 72.4 us, step 0.501 -> 0.510 ms.  The
-        // weight traffic halves, but 100 rows cut into 16-row pairs waste 12 % of the tile rows (8-row tiles: 4 %) and
-        // eight waves in lockstep on one barrier hide each other's waits worse than two independent 4-wave groups.
-        // (Tall 16 x 16 x 64-channel tiles, LSS_CONV_BN64=1, share a slab the same way with 4-wave barriers: 64.3 ->
-        // 75.1 us, same row waste.)  Bitwise the plain launch's result.
-        const char* epsp = getenv("LSS_CONV_PSP");
-        const bool psp = nwg2 >= 512 && epsp != nullptr && atoi(epsp) != 0;
-        if (psp) {
-          const int tilesYp = lss_cdiv(a.Ho, 2 * th2);
-          hipLaunchKernelGGL((conv_lds_kernel<2, 128, MODE, KH, KW, PAD, 64, 1, false, false, 2>),
-                             dim3(tilesX * tilesYp * a.B, nblk), dim3(512), 0, st, a, tilesX, tilesYp);
           return;
         }
       }
@@ -1398,7 +1252,7 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   a.y2 = nullptr; a.split = 0; a.relu_n = a.Cout;
   const bool head_major = (relu & LSS_OUT_HEAD_MAJOR32) != 0;
   if (a.relu == 3 || (relu & ~(3 | LSS_OUT_F32 | LSS_OUT_HEAD_MAJOR32)) != 0) return LSS_E_LAYOUT;
-  a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0; a.head_valu = 0;
+  a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0;
   a.ry = a.Hin > 1 ? (float)(H - 1) / (float)(a.Hin - 1) : 0.f;
   a.rx = a.Win > 1 ? (float)(W - 1) / (float)(a.Win - 1) : 0.f;
   const bool fused = (up > 1) || (C2 > 0);
@@ -1461,7 +1315,7 @@ static int conv2d_s2_impl(const void* x, const void* w_s2d, const float* scale, 
   a.wt = (getenv("LSS_CONV_WT") == nullptr || atoi(getenv("LSS_CONV_WT")) != 0) &&
          (unsigned long long)a.M * a.Cout * 2 < (1ULL << 31);
   a.y2 = y2; a.split = split; a.relu_n = y2 ? relu_n : a.Cout;
-  a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0; a.head_valu = 0;
+  a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_n = 0;
   a.ry = a.rx = 0.f;
   hipStream_t st = lss_stream(stream);
   if (K == 7) launch_conv_lds<2, 4, 4, 2>(a, st);
@@ -1531,7 +1385,6 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
          (unsigned long long)a.M * a.Cout * 2 < (1ULL << 31);
   a.y2 = nullptr; a.split = 0; a.relu_n = a.Cout;
   a.head_w = head_w; a.head_b = head_b; a.head_out = out; a.head_n = head_n;
-  a.head_valu = getenv("LSS_CONV_HEAD_VALU") != nullptr && atoi(getenv("LSS_CONV_HEAD_VALU")) != 0;
   a.ry = a.Hin > 1 ? (float)(H - 1) / (float)(a.Hin - 1) : 0.f;
   a.rx = a.Win > 1 ? (float)(W - 1) / (float)(a.Win - 1) : 0.f;
   const bool fused = (up > 1) || (C2 > 0);
@@ -1543,10 +1396,7 @@ extern "C" int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_
   if (const char* e = getenv("LSS_CONV_KC")) kc32 = kc32 && atoi(e) == 32;
   if (fused && kc32) {
     a.src_lds = conv_src_lds_ok(a);
-    if (a.src_lds && conv_pfb_on())
-      hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1, 32, 1, true, true>), g, dim3(256), 0, st, a, tilesX, tilesY);
-    else
-      hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1, 32, 1, true>), g, dim3(256), 0, st, a, tilesX, tilesY);
+    hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1, 32, 1, true>), g, dim3(256), 0, st, a, tilesX, tilesY);
   }
   else if (fused)
     hipLaunchKernelGGL((conv_lds_kernel<2, 128, 1, 3, 3, 1, 64, 1, true>), g, dim3(256), 0, st, a, tilesX, tilesY);

@@ -273,7 +273,7 @@ constexpr int FX_MAGIC_HI = 0x43380000;
 template <int CPL>
 __device__ __forceinline__ void region_accumulate_careful(const float* __restrict__ feat,
                                                           const int2* __restrict__ entries, int start, int n,
-                                                          double scale, unsigned long long* tile,
+                                                          double scale, float limit, unsigned long long* tile,
                                                           unsigned int* flags, int wave, int lane) {
   constexpr int C = 64 * CPL;
   for (int c0 = wave * 64; c0 < n; c0 += 256) {
@@ -292,7 +292,7 @@ __device__ __forceinline__ void region_accumulate_careful(const float* __restric
       for (int q = 0; q < CPL; ++q) {
         const float x = ww * feat[(size_t)(k >> 8) * C + q * 64 + lane];
         const int o = (k & 255) * C + q * 64 + lane;
-        if (!(fabsf(x) <= 3.0e38f)) {
+        if (!(fabsf(x) < limit)) {  // non-finite, or beyond what the fixed-point accumulator holds: the cell reads NaN
           atomicOr(&flags[o >> 5], 1u << (o & 31));
         } else {
           const double t = __builtin_fma((double)x, scale, FX_MAGIC);
@@ -334,16 +334,21 @@ __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restri
   unsigned int* flags = reinterpret_cast<unsigned int*>(tile + (size_t)ncell * C);  // [ncell*C/32]
   const int n = rp.region_count[r];
   const int start = rp.region_start[r];
-  const float m = rp.wg_absmax[rp.n2];  // max |feature| over K2's workgroups (reduced by the fill kernel)  // max |feature| over K2's workgroups (reduced by the fill kernel)
+  const float m = rp.wg_absmax[rp.n2];  // max FINITE |feature| over K2's workgroups (reduced by the fill kernel)
   if (tid == 0) wg_watch = 0;
   __syncthreads();  // every thread has read region_count[r]
   if (tid == 0) {   // the counters go back to zero (workspace contract)
     rp.region_count[r] = 0;
     rp.region_cursor[r] = 0;
   }
+  // Every finite product is |depth weight (<= 1) x feature| <= m < 2^e, so |x * 2^(40-e)| < 2^40: far inside the
+  // 2^51 the magic-number conversion holds.  A product at or above 2^(e+10) can only come from a non-finite operand
+  // or from weights above 1 (no caller has them); `watch` sends the region to the careful path in either case.
   int e = 0;
-  if (m > 0.f && m < INFINITY) (void)frexpf(m, &e);  // m < 2^e
+  if (m > 0.f && m <= 3.0e38f) (void)frexpf(m, &e);  // m < 2^e
+  e = max(e, -80);  // all-tiny features: keep 2^(40-e) and its reciprocals finite in fp32
   const double scale = ldexp(1.0, 40 - e);
+  const unsigned int watch_limit = __builtin_bit_cast(unsigned int, ldexpf(1.0f, min(e + 10, 127)));
   const float inv_lo = ldexpf(1.0f, e - 40), inv_hi = ldexpf(1.0f, e - 8);  // 2^-(40-e), and x 2^32
   const int zero_n = ncell * C / 2 + ncell * C / 128;  // 16-B stores that clear the sums and the flag words
 
@@ -404,21 +409,23 @@ __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restri
         w = __builtin_bit_cast(float, en.y);
       }
     }
-    if (watch >= 0x7f800000u) atomicOr(&wg_watch, 1u);
+    if (watch >= watch_limit) atomicOr(&wg_watch, 1u);  // a non-finite (or impossibly large) product went by
     __syncthreads();
     if (stp != nullptr && tid == 0) stp[2] = __builtin_amdgcn_s_memrealtime();
     if (wg_watch != 0) {  // rare: a non-finite product - redo the region element by element, with flags
       __syncthreads();
       for (int i = tid; i < zero_n; i += 256) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
       __syncthreads();
-      region_accumulate_careful<CPL>(feat, entries, start, n, scale, tile, flags, wave, lane);
+      region_accumulate_careful<CPL>(feat, entries, start, n, scale, ldexpf(1.0f, min(e + 10, 127)), tile, flags, wave, lane);
       __syncthreads();
     }
   }
 
   auto value = [&](int o) -> float {  // (cell, channel) element o of the tile as fp32
-    // int64 -> fp32 on the fp32 pipe: hi * 2^32 * 2^-s + lo * 2^-s (hi, lo the two words; |sum| < 2^56 keeps
-    // the conversion of hi exact, so the result is within one rounding of the exact quotient)
+    // int64 -> fp32 on the fp32 pipe: hi * 2^32 * 2^-s + lo * 2^-s (hi, lo the two words).  |sum| < 2^56 (terms below
+    // 2^40, fewer than 2^16 of them in a cell) keeps the conversion of hi exact and the result within one rounding of
+    // the exact quotient; a cell with more terms than that (hi-res rigs can put > 65536 points in ONE cell only with
+    // degenerate calibrations) pays one more fp32 rounding, nothing worse: hi stays far inside int32.
     const unsigned long long sv = tile[o];
     const float v = __builtin_fmaf((float)(int)(sv >> 32), inv_hi, (float)(unsigned int)sv * inv_lo);
     return ((flags[o >> 5] >> (o & 31)) & 1u) ? __builtin_nanf("") : v;
@@ -641,7 +648,10 @@ static bool region_plan_for(int B, int N, int D, int fH, int fW, int C, int X, i
   rp->n2 = lss_region_k2_blocks(B, N, fH, fW);
   const long long nreg = (long long)B * rp->rps;
   const size_t tile_bytes = (size_t)64 * Z * C * 8 + (size_t)64 * Z * C / 8;
-  if (rp->rps > 4096 || tile_bytes > 64 * 1024 || 64 * Z > 256 || P >= (1LL << 22) || nreg >= (1LL << 24) ||
+  // (cell index of an entry: 8 bits -> 64 * Z <= 256; the int64 tile: up to 128 KiB of the CU's 160 KiB, opted into
+  // per instantiation with hipFuncSetAttribute - C = 128 and Z = 2 used to be turned away at 64 KiB and ran on the
+  // voxel-list pipeline without any test noticing)
+  if (rp->rps > 4096 || tile_bytes > 130 * 1024 || 64 * Z > 256 || P >= (1LL << 22) || nreg >= (1LL << 24) ||
       (long long)B * N * fH * fW >= (1LL << 23))
     return false;
   if (2 * nreg > nvox || nreg + rp->n2 + 1 > 2 * nvox) return false;
@@ -650,6 +660,15 @@ static bool region_plan_for(int B, int N, int D, int fH, int fW, int C, int X, i
   rp->region_start = vox_list;
   rp->wg_absmax = reinterpret_cast<float*>(vox_list + nreg);
   return true;
+}
+
+// Does lss_lift_splat_forward run this problem on the region-bucketed pipeline (f32 depthnet math assumed)?  The same
+// limits as region_plan_for, without touching a workspace: lets a test assert which pipeline produced its result.
+extern "C" int lss_region_pipeline_ok(int B, int N, int D, int fH, int fW, int C, int X, int Y, int Z) {
+  if (B <= 0 || N <= 0 || D <= 0 || fH <= 0 || fW <= 0 || X <= 0 || Y <= 0 || Z <= 0 || (C != 64 && C != 128)) return 0;
+  static int32_t dummy[4];
+  LssRegionPlan rp;
+  return region_plan_for(B, N, D, fH, fW, C, X, Y, Z, dummy, dummy, &rp) ? 1 : 0;
 }
 
 static int region_splat_launch(const float* feat, const int32_t* entries, const LssRegionPlan& rp, int B, int C, int X,
@@ -661,8 +680,22 @@ static int region_splat_launch(const float* feat, const int32_t* entries, const 
   unsigned long long* stamps = getenv("LSS_L1_STAMPS")
       ? reinterpret_cast<unsigned long long*>(strtoull(getenv("LSS_L1_STAMPS"), nullptr, 16)) + (size_t)16384 * 8 : nullptr;
   static const int centre_out = getenv("LSS_SPLAT_ORDER") == nullptr || atoi(getenv("LSS_SPLAT_ORDER")) != 0;
-#define LSS_RS(CPL, LAY) \
-  hipLaunchKernelGGL((region_splat_kernel<CPL, LAY>), grid, dim3(256), lds, st, feat, en, rp, X, Y, Z, bev, stamps, centre_out)
+#define LSS_RS(CPL, LAY)                                                                                          \
+  do {                                                                                                            \
+    if (lds > 64 * 1024) {                                                                                        \
+      static bool big[16] = {};                                                                                   \
+      int dev = 0;                                                                                                \
+      (void)hipGetDevice(&dev);                                                                                   \
+      if (dev >= 0 && dev < 16 && !big[dev]) {                                                                    \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&region_splat_kernel<CPL, LAY>),                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024) != hipSuccess)            \
+          return LSS_E_SHAPE;                                                                                     \
+        big[dev] = true;                                                                                          \
+      }                                                                                                           \
+    }                                                                                                             \
+    hipLaunchKernelGGL((region_splat_kernel<CPL, LAY>), grid, dim3(256), lds, st, feat, en, rp, X, Y, Z, bev,     \
+                       stamps, centre_out);                                                                       \
+  } while (0)
   if (C == 64) {
     if (layout == LSS_BEV_NCHW_F32) LSS_RS(1, LSS_BEV_NCHW_F32);
     else if (layout == LSS_BEV_NHWC_F32) LSS_RS(1, LSS_BEV_NHWC_F32);

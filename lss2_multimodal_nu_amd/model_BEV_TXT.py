@@ -4,15 +4,17 @@
 Same constructor arguments, same `forward(x, rots, trans, intrins, post_rots,
 post_trans)` signature, same public methods (`create_frustum`, `get_geometry`,
 `get_cam_feats`, `voxel_pooling`, `get_voxels`), same `state_dict` entries
-(`dx bx nx frustum camencode.* bevencode.*` ...).  Underneath, the camera->BEV
-path is five HIP launches (csrc/):
+(`dx bx nx frustum camencode.* bevencode.*` ...).  Underneath, the inference
+camera->BEV path is three HIP launches behind ONE native call (csrc/, DESIGN.md
+section 3):
 
-    K2 depthnet+softmax  ||  K3 points->voxels(+histogram) -> K4 alloc, fill
-                         \\________________________________________________/
-                                               K5 fused lift-splat
+    [K2 depthnet + softmax  ||  K3 points -> voxels, region histograms in LDS]   one launch
+        -> K4r region fill (entries grouped by 8 x 8-cell region, no sort)
+        -> K5r region splat (fixed-point LDS sums, coalesced BEV stores incl. zeros)
 
 and the lifted (B,N,D,fH,fW,C) tensor, the sort, the cumsum and the zero-filled
-scatter target of the reference never exist.
+scatter target of the reference never exist.  The autograd path and the API-compat
+entries (`voxel_pooling`, `get_geometry`) use the voxel-list form K3 -> K4 -> K5 / K7.
 
 What is NOT here: the EfficientNet-B4 trunk (`Encoder`, third-party weights, a
 network fetch).  `encoder=` accepts any module producing the (B*N, 512, fH, fW)

@@ -5,12 +5,16 @@ Constructor signatures, `forward()` signatures, parameter names / shapes and the
 default initialisation follow the reference (and torchvision 0.13.1's resnet18
 for `layer1..3`), so a reference `state_dict` loads with `strict=True` into the
 corresponding module here.  torch.nn modules are used as PARAMETER CONTAINERS;
-the inference arithmetic runs in the HIP kernels of csrc/ (conv_mfma.hip,
-depthnet.hip) through the C ABI - there is no eager fallback for it.
+the inference arithmetic runs in the HIP kernels of csrc/ (conv_mfma.hip and, for
+the three big 3x3 layers at the sizes it takes, conv_ring.hip; depthnet.hip) through
+the C ABI - there is no eager fallback for it.
 
-Training mode (batch-statistics BatchNorm + autograd through the convs) is not
-native yet: it runs the same parameters through torch's GPU ops (MIOpen).  See
-DESIGN.md "Out of scope / not yet native".
+Training mode under bf16 autocast: every `conv3x3/s1 -> BatchNorm(train) -> (+residual)
+-> ReLU` unit (95 % of BevEncode's FLOPs, the fused upsample + concat input of `Up`
+included) is ONE autograd node on the HIP kernels (conv forward / dgrad / wgrad,
+batch-statistics BN forward / backward: conv_grad.hip, bn_train.hip); the 7x7/2 stem,
+the stride-2 and 1x1 convs and plain-fp32 training run the same parameters through
+torch's GPU ops.  See DESIGN.md section 9.
 """
 import os
 

@@ -479,54 +479,6 @@ def test_k8_conv_tile_variants_agree(ops, rt, monkeypatch):
         assert float((out - ref).abs().max()) <= BF16_OUT_TOL * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("shape", [(4, 100, 100, 256, 256, True), (2, 100, 100, 128, 256, False), (3, 72, 90, 64, 128, True)])
-def test_k8_mixed_tile_launch(ops, monkeypatch, shape):
-    """Grids that end in a partial round of resident slots run as full-height tiles over the top rows + half-height
-    tiles over the rest (conv_lds_mixed_kernel): bitwise the plain launch's result (same K order per pixel), and right
-    against torch.  (4, 100, 100, 256 -> 256) is BevEncode's up1.conv3 at the bench batch."""
-    B, H, W, Cin, Cout, use_res = shape
-    gen = torch.Generator().manual_seed(sum(shape[:5]))
-    x = _q(torch.randn(B, Cin, H, W, generator=gen), 1)
-    w = _q(torch.randn(Cout, Cin, 3, 3, generator=gen) * (Cin * 9) ** -0.5, 1)
-    scale, shift = torch.rand(Cout, generator=gen) + 0.5, torch.randn(Cout, generator=gen) * 0.1
-    res = _q(torch.randn(B, Cout, H, W, generator=gen), 1) if use_res else None
-    ref = torch.nn.functional.conv2d(x, w, None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
-    if use_res:
-        ref = ref + res
-    ref = ref.relu()
-    xg, wp = ops.nchw_to_nhwc(x.cuda(), 1), ops.pack_conv_weight(w.cuda(), 1)
-    rg = ops.nchw_to_nhwc(res.cuda(), 1) if use_res else None
-    monkeypatch.setenv("LSS_CONV_MIXED", "1")
-    y_mixed = ops.conv2d_nhwc(xg, wp, (3, 3), 1, 1, scale.cuda(), shift.cuda(), rg, True, dt=1)
-    monkeypatch.setenv("LSS_CONV_MIXED", "0")
-    y_plain = ops.conv2d_nhwc(xg, wp, (3, 3), 1, 1, scale.cuda(), shift.cuda(), rg, True, dt=1)
-    assert torch.equal(y_mixed, y_plain)
-    out = ops.nhwc_to_nchw(y_mixed, 1).cpu()
-    assert float((out - ref).abs().max()) <= BF16_OUT_TOL * float(ref.abs().max())
-
-
-@pytest.mark.parametrize("switch", ["LSS_CONV_PSP", "LSS_CONV_BN64"])
-@pytest.mark.parametrize("shape", [(4, 100, 100, 256, 256, True), (4, 104, 90, 128, 256, False)])
-def test_k8_shared_slab_variants(ops, monkeypatch, shape, switch):
-    """The two measured-and-switched-off ways of sharing a weight slab over more pixels:
-    512-thread pixel-split pairs on one ring (LSS_CONV_PSP=1; 100 rows = 6 pairs + a pair whose second tile lies
-    outside the image) and tall 16 x 16 x 64-channel tiles (LSS_CONV_BN64=1).  Same K order per output element as the
-    plain launch: bitwise equal."""
-    B, H, W, Cin, Cout, use_res = shape
-    gen = torch.Generator().manual_seed(sum(shape[:5]) + 1)
-    x = _q(torch.randn(B, Cin, H, W, generator=gen), 1)
-    w = _q(torch.randn(Cout, Cin, 3, 3, generator=gen) * (Cin * 9) ** -0.5, 1)
-    scale, shift = torch.rand(Cout, generator=gen) + 0.5, torch.randn(Cout, generator=gen) * 0.1
-    res = _q(torch.randn(B, Cout, H, W, generator=gen), 1) if use_res else None
-    xg, wp = ops.nchw_to_nhwc(x.cuda(), 1), ops.pack_conv_weight(w.cuda(), 1)
-    rg = ops.nchw_to_nhwc(res.cuda(), 1) if use_res else None
-    monkeypatch.setenv(switch, "1")
-    y_var = ops.conv2d_nhwc(xg, wp, (3, 3), 1, 1, scale.cuda(), shift.cuda(), rg, True, dt=1)
-    monkeypatch.setenv(switch, "0")
-    y_plain = ops.conv2d_nhwc(xg, wp, (3, 3), 1, 1, scale.cuda(), shift.cuda(), rg, True, dt=1)
-    assert torch.equal(y_var, y_plain)
-
-
 def test_k8_stem_two_taps_per_step(ops, monkeypatch):
     """7x7 / 2 stem: steps of two taps against a double slab (the default) = steps of one tap, bitwise."""
     gen = torch.Generator().manual_seed(5)

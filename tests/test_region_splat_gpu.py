@@ -97,6 +97,10 @@ CASES = [
 def test_region_pipeline_vs_fp64_and_voxel_list_pipeline(ops, monkeypatch, report, case, layout):
     B, N, D, fH, fW, C, grid, fd, rc = CASES[case]
     pr = problem(B, N, D, fH, fW, C, grid, fd, seed=case, randn_calib=rc)
+    # every case - including Z = 2 (CASES[1]) and C = 128 (CASES[2]), whose 64-KiB+ LDS tiles used to be turned away
+    # silently - must really run on the region pipeline
+    X_, Y_, Z_ = problem(B, N, D, fH, fW, C, grid, fd, seed=case, randn_calib=rc)["nx"]
+    assert ops.N.lib().lss_region_pipeline_ok(B, N, D, fH, fW, C, X_, Y_, Z_) == 1
     bev, depth, feat, ws = run(ops, pr, layout, False, monkeypatch)
     bev_l, depth_l, feat_l, ws_l = run(ops, pr, layout, True, monkeypatch)
     X, Y, Z = pr["nx"]
@@ -173,6 +177,40 @@ def test_region_pipeline_nonfinite_feature_stays_in_its_cells(ops, monkeypatch):
             touched[b, idx[b, n, d, 2, 7, 0], idx[b, n, d, 2, 7, 1]] = True
     changed = (bad != clean) & ~(torch.isnan(bad) & torch.isnan(clean))
     assert not bool(changed.cpu().any(1)[~touched].any())
+    assert int(ws.vox_count.abs().sum()) == 0
+
+
+def test_region_pipeline_inf_feature_beside_large_finite_ones(ops, monkeypatch, report):
+    """VERDICT r2 / ADVICE r2: with one +inf context feature in the call, the fixed-point scale must still come from
+    the largest FINITE feature.  Features of magnitude ~1e4: before the fix the inf maximum fell back to scale 2^40,
+    |x * 2^40| >= 2^51 broke the magic-number conversion, and cells the bad pixel never touches came out wrong."""
+    B, N, D, fH, fW, C, grid, fd, rc = CASES[0]
+    pr = problem(B, N, D, fH, fW, C, grid, fd, seed=9)
+    pr["w"] = pr["w"].clone()
+    pr["w"][D:] *= 1.0e4                      # context rows of the depthnet: features ~1e4
+    pr["bias"] = pr["bias"].clone()
+    pr["bias"][D:] *= 1.0e4
+    clean, depth, feat, ws = run(ops, pr, 1, False, monkeypatch)
+    clean = clean.clone()
+    assert float(feat.abs().max()) > 5.0e3
+    ref, idx, kept = oracle_bev(pr, depth, feat)
+    e_clean = report("region_splat large features: max err / max|ref|",
+                     np.abs(clean.double().cpu().numpy() - ref).max() / np.abs(ref).max())
+    assert e_clean <= 2e-7
+    pr2 = dict(pr)
+    x = pr["x"].clone()
+    x[3, :, 2, 7] = float("inf")             # one camera pixel: all of its context features become inf / NaN
+    pr2["x"] = x
+    bad, depth2, feat2, _ = run(ops, pr2, 1, False, monkeypatch, ws=ws)
+    assert not bool(torch.isfinite(feat2).all())
+    b, n = 3 // N, 3 % N
+    touched = torch.zeros(B, pr["nx"][0], pr["nx"][1], dtype=torch.bool)
+    for d in range(D):
+        if kept[b, n, d, 2, 7]:
+            touched[b, idx[b, n, d, 2, 7, 0], idx[b, n, d, 2, 7, 1]] = True
+    assert bool((~torch.isfinite(bad)).cpu().any(1)[touched].any())   # the poisoned cells read non-finite ...
+    same = (bad == clean) | (torch.isnan(bad) & torch.isnan(clean))
+    assert bool(same.cpu().all(1)[~touched].all())                     # ... and every other cell is bit-identical
     assert int(ws.vox_count.abs().sum()) == 0
 
 

@@ -57,10 +57,6 @@ def main():
     if f and wr:
         js = os.path.join(dst, rnd + "_hbm_traffic.json")
         w("hbm_traffic.txt", run_tool("pmc_traffic.py", f, wr, js))
-    wn = find(os.path.join(src, "write_nospill"), "*counter_collection.csv")
-    if f and wn:
-        w("hbm_traffic_nospill.txt", "# LSS_CONV_PFB=1 (the fused upsample convs' 228-VGPR build: no scratch, 2 workgroups per CU); FETCH "
-          "columns are the default build's\n" + run_tool("pmc_traffic.py", f, wn))
     sq, sqkt = find(os.path.join(src, "sq"), "*counter_collection.csv"), find(os.path.join(src, "sq"), "*kernel_trace.csv")
     if sq and sqkt:
         head = ("# rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS "

@@ -24,9 +24,6 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $R/bench.py $ARGS > $OUT/kt.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python $R/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python $R/bench.py $ARGS > $OUT/write.log 2>&1
-# the same WRITE_SIZE pass with the spill-free (2 workgroups / CU) build of the fused upsample convs: separates scratch
-# write-backs from the kernels' own stores ("WRITE_SIZE above the algorithmic bytes")
-LSS_CONV_PFB=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write_nospill -- python $R/bench.py $ARGS > $OUT/write_nospill.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/sq -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-train --no-two-streams > $OUT/sq.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_hires -- python $R/bench.py --workload hires $ARGS > $OUT/kt_hires.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_fp32 -- python $R/bench.py --precision fp32 --steps 10 --warmup 3 --no-cpu-baseline --no-train --no-two-streams > $OUT/kt_fp32.log 2>&1
