@@ -60,7 +60,7 @@ struct RingArgs {
   int B, H, W, Cx, C2, up, Hin, Win, Cin, Cout, relu, wt;
   float ry, rx;
   int SX, SY, nstrips, nblk, nch;
-  // diagnostics (LSS_RING_STATS=<hex device address>): per workgroup 6 waves x 4 u64: {polls spent waiting on the
+  // diagnostics (LSS_RING_STATS=<hex device address>): per workgroup 12 waves x 6 u64: {polls spent waiting on the
   // first / second kind of flag, 100-MHz ticks from kernel entry to the wave's end, ticks at entry}
   unsigned long long* stats;
 };
@@ -96,11 +96,12 @@ typedef __attribute__((address_space(3))) volatile int* rk_flag_t;
 // wave-uniform read of a flag word
 __device__ __forceinline__ int rk_peek(rk_flag_t f) { return __builtin_amdgcn_readfirstlane(*f); }
 // wait until *f >= need (bounded)
+template <int SLEEP = 1>
 __device__ __forceinline__ int rk_wait_ge(rk_flag_t f, int need) {
   int v = rk_peek(f);
   int n = 0;
   while (v < need) {
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(SLEEP);  // units of 64 cycles
     v = rk_peek(f);
     if (++n > RK_SPIN_LIMIT) {
       if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&lss_ring_timeouts, 1);
@@ -162,6 +163,9 @@ __device__ __forceinline__ uint4 rk_blend(const uint4& q00, const uint4& q01, co
 // consumers 0 / patch loaders 3 / weight loader 2: 211.0 us; 2 / 0 / 3: 220.5; 0 / 0 / 0: 220.6; 1 / 0 / 3: 220.1 -
 // the blend has to be served promptly (the consumers wait for the patch at every chunk boundary), the MFMAs find
 // their slots anyway.
+#ifndef RK_PSLEEP
+#define RK_PSLEEP 8  // s_sleep argument of the patch loaders' polls for the consumers' release (x 64 cycles)
+#endif
 #ifndef RK_PRIO_C
 #define RK_PRIO_C 0
 #endif
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
   const unsigned long long t_entry = a.stats ? __builtin_amdgcn_s_memrealtime() : 0ull;
   auto write_stats = [&]() {
     if (a.stats != nullptr && lane == 0) {
-      unsigned long long* o = a.stats + ((size_t)blockIdx.x * RK_NWAVES + wave) * 4;
+      unsigned long long* o = a.stats + ((size_t)blockIdx.x * RK_NWAVES + wave) * 6;
       o[0] = (unsigned long long)st0; o[1] = (unsigned long long)st1;
       o[2] = __builtin_amdgcn_s_memrealtime() - t_entry; o[3] = t_entry;
     }
@@ -382,7 +386,8 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
           rk_add1(flags + F_FULL_P + ((c + 1) & 1), lane);
         }
         if (c + 2 < a.nch) {
-          st0 += rk_wait_ge(flags + F_FREE_P + (c & 1), RK_NCONS * ((c >> 1) + 1));  // the consumers are done with chunk c
+          // (polled every 512 cycles: the wait is a chunk long and the loaders' polls take issue slots from the consumers)
+          st0 += rk_wait_ge<RK_PSLEEP>(flags + F_FREE_P + (c & 1), RK_NCONS * ((c >> 1) + 1));  // the consumers are done with chunk c
           issue_full(c + 2, c & 1);
         }
       }
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
       // released it; upsampled chunk: the source window, once ALL patch loaders have finished blending from it.
       auto prepare = [&](int c) {
         if (c < nskip) {
-          st0 += rk_wait_ge(flags + F_FREE_P + (c & 1), RK_NCONS * (c >> 1));
+          st0 += rk_wait_ge<RK_PSLEEP>(flags + F_FREE_P + (c & 1), RK_NCONS * (c >> 1));
           issue_full(c, c & 1);
         } else {
           st1 += rk_wait_ge(flags + F_FREE_S, RK_NPATCH * (c - nskip));
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
           // every loader's share of the source window has landed / the consumers have released the patch buffer
           rk_add1(flags + F_FULL_S, lane);
           st1 += rk_wait_ge(flags + F_FULL_S, RK_NPATCH * (c - nskip + 1));
-          st0 += rk_wait_ge(flags + F_FREE_P + (c & 1), RK_NCONS * (c >> 1));
+          st0 += rk_wait_ge<RK_PSLEEP>(flags + F_FREE_P + (c & 1), RK_NCONS * (c >> 1));
           unsigned char* dst = smem + L::PATCH + (c & 1) * (RK_NS * RK_STRIP_PATCH);
           // fully unrolled (static register indices for g_off / g_w), no branches (a piece outside the image blends
           // whatever sits at offset 0 of the window and is replaced by zeros afterwards), and the four corner reads of
@@ -512,6 +517,7 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
                  : "memory");
   };
 
+  RK_ST(const unsigned long long tc_loop = __builtin_amdgcn_s_memtime(); const unsigned long long tr_loop = __builtin_amdgcn_s_memrealtime();)
   int slot = 0, gen = 1, buf = 0, pgen = 1;
   rk_wait_ge(flags + F_FULL_P + 0, RK_NPATCH);
   rk_wait_ge(flags + F_FULL_W + 0, 1);
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
     step(std::integral_constant<int, 8>{}, c + 1 == a.nch);
   }
 #undef RK_DSR
-  RK_ST(if (a.stats != nullptr && lane == 0) a.stats[((size_t)blockIdx.x * RK_NWAVES + wave) * 4 + 2] = __builtin_amdgcn_s_memrealtime() - t_entry;)  // end of the main loop
+  RK_ST(if (a.stats != nullptr && lane == 0) { unsigned long long* o = a.stats + ((size_t)blockIdx.x * RK_NWAVES + wave) * 6; o[2] = __builtin_amdgcn_s_memrealtime() - t_entry; o[4] = __builtin_amdgcn_s_memtime() - tc_loop; o[5] = __builtin_amdgcn_s_memrealtime() - tr_loop; })  // end of the main loop: ticks, shader cycles and 100-MHz ticks of the loop
 
   // ---- epilogue: lane (q = kq, n) holds channels ch0 .. ch0 + 15 of pixel n of every block ----
   const int ch0 = T.nb * 128 + cg * 64 + kq * 16;
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
     }
   }
   RK_ST(if (a.stats != nullptr && lane == 0) {
-    unsigned long long* o = a.stats + ((size_t)blockIdx.x * RK_NWAVES + wave) * 4;
+    unsigned long long* o = a.stats + ((size_t)blockIdx.x * RK_NWAVES + wave) * 6;
     o[0] = (unsigned long long)st0; o[1] = (unsigned long long)st1; o[3] = t_entry;
   })
 #undef RK_ST

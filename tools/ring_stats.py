@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
-    buf = torch.zeros(4096 * 12 * 4, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(4096 * 12 * 6, dtype=torch.int64, device="cuda")
     os.environ["LSS_RING_STATS"] = "%x" % buf.data_ptr()
     from lss2_multimodal_nu_amd import ops
     from bench_ring import LAYERS
@@ -38,7 +38,7 @@ def main():
         run()
         torch.cuda.synchronize()
         nwg = (B * ((H * up + 3) // 4) * ((W * up + 19) // 20) + 3) // 4 * (Cout // 128)
-        st = buf[:nwg * 48].view(nwg, 12, 4).cpu().double()
+        st = buf[:nwg * 72].view(nwg, 12, 6).cpu().double()
         t0 = st[:, :, 3].min()
         print("%s: %d workgroups, %d chunks" % (name, nwg, (Cx + C2) // 32))
         for role, sl, n0, n1 in (("consumer", slice(0, 8), "polls on FULL_W (slab late)", "polls on FULL_P (patch late)"),
@@ -49,7 +49,9 @@ def main():
                   % (role, n0, s[..., 0].mean(), s[..., 0].max(), n1, s[..., 1].mean(), s[..., 2].mean() / 100,
                      s[..., 2].max() / 100, (s[..., 3] - t0).mean() / 100))
         end = (st[:, :8, 3] + st[:, :8, 2]).max() - t0
-        print("  first entry -> last consumer loop end: %.1f us" % (end / 100))
+        clk = st[:, :8, 4] / (st[:, :8, 5] / 100.0)  # shader cycles per us of the consumers' main loop
+        print("  first entry -> last consumer loop end: %.1f us; in-kernel clock over the consumer loops: median %.0f MHz "
+              "(min %.0f, max %.0f)" % (end / 100, float(clk.median()), float(clk.min()), float(clk.max())))
 
 
 if __name__ == "__main__":
