@@ -778,7 +778,7 @@ extern "C" int lss_conv2d_ring_ok(int B, int H, int W, int Cx, int C2, int up, i
   if ((long long)B * H * W * (long long)Cx >= (1LL << 31) || (long long)B * Hin * Win * (long long)(C2 > 0 ? C2 : 1) >= (1LL << 31))
     return 0;
   const long long strips = (long long)B * lss_cdiv(Hin, RK_SH) * lss_cdiv(Win, RK_SW);
-  return strips / RK_NS * (Cout / 128) >= 128 ? 1 : 0;
+  return strips / RK_NS * (Cout / 128) >= 96 ? 1 : 0;
 }
 
 // Number of flag waits of the ring kernel that ran into their bound since the module was loaded (synchronises the
