@@ -23,7 +23,6 @@ SOURCES = {
     "depthnet.hip": [],
     "splat.hip": [],
     "conv_mfma.hip": [],
-    "conv_ksplit.hip": [],
     "conv_ring.hip": ["-fno-slp-vectorize"],  # no v_pk_*_f32 next to MFMAs (MI355X_MICROARCH.md)
     "layout.hip": [],
     "bev_transformer.hip": [],

@@ -24,9 +24,6 @@ int lss_linear_bf16_launch(const void* x, const void* w, const float* scale, con
                            const void* residual, void* y, long long M, int N, int K, int act,
                            int out_f32, int group_hw, hipStream_t st);  // linear_mfma.hip
 
-int lss_conv_ksplit_ok(int B, int H, int W, int Cin, int Cout);  // conv_ksplit.hip
-int lss_conv_ksplit_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
-                           void* y, int B, int H, int W, int Cin, int Cout, int relu, int wt, hipStream_t st);
 int lss_conv_ring_launch(const void* x, const void* x2, const void* w_ring, const float* scale, const float* shift,
                          void* y, const float* head_w, const float* head_b, float* head_out, int head_n, int B, int H,
                          int W, int Cx, int C2, int up, int Cout, int relu, int wt, hipStream_t st);  // conv_ring.hip
@@ -1264,9 +1261,6 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   hipStream_t st = lss_stream(stream);
   if (dt == LSS_DT_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && a.Cin % 64 == 0 &&
       getenv("LSS_CONV_DIRECT") == nullptr) {
-    // the launch-bound resnet layers: K split over the waves of a workgroup, operands straight from global memory
-    if (!fused && stats == nullptr && !a.out_f32 && a.relu <= 1 && lss_conv_ksplit_ok(B, H, W, Cx, Cout))
-      return lss_conv_ksplit_launch(x, w_packed, scale, shift, residual, y, B, H, W, Cx, Cout, a.relu, a.wt, st);
     if (fused) launch_conv_lds<1, 3, 3, 1>(a, st);
     else launch_conv_lds<0, 3, 3, 1>(a, st);
     return lss_launch_status();
