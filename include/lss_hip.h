@@ -428,6 +428,18 @@ int lss_conv2d_head_fwd(const void* x, const void* x2, const void* w_packed, con
                         int B, int H, int W, int Cx, int C2, int up, int Cout, int head_n,
                         int relu, void* stream);
 
+/* Lift-splat of depth / context tensors that other kernels produced - the vovnet model's depth heads and
+ * CamEncodeV2 (replaces src/model_vovnet_transformer.py:513-554 `get_voxels`' geometry + voxel_pooling for those
+ * tensors): K3 geometry, bucketing and splat behind one call, on the region-bucketed pipeline when the problem fits
+ * it (lss_region_pipeline_ok; C = 64 or 128), else K3 -> K4 -> K5.
+ *   depth (B*N, D, fH, fW) fp32 softmax weights; feat (B*N*fH*fW, C) fp32 channels-last context
+ *   workspace words as lss_lift_splat_forward; bev / layout as lss_lift_splat_fwd */
+int lss_lift_splat_from_heads(const float* frustum, const float* inv_post_rots, const float* post_trans,
+                              const float* combine, const float* trans, const float* dx, const float* bx,
+                              const float* depth, const float* feat, int B, int N, int D, int fH, int fW, int C,
+                              int X, int Y, int Z, int32_t* voxel, int32_t* vox_count, int32_t* vox_list,
+                              int32_t* entries, int32_t* cursor, void* bev, int layout, void* stream);
+
 /* 1 when lss_lift_splat_forward (f32 depthnet math) runs (B,N,D,fH,fW,C | X,Y,Z) on the region-bucketed pipeline
  * (K2 || K3 with LDS region histograms -> region fill -> fixed-point region splat), 0 when the problem exceeds its
  * limits and the voxel-list pipeline (K3, K4, K2, K5) is used.  Honours LSS_SPLAT_LEGACY. */

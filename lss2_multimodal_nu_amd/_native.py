@@ -74,6 +74,7 @@ SIGNATURES = {
     "lss_conv2d_sequence": (_i, [_vp, _i, _vp]),
     "lss_lift_splat_forward": (_i, [_vp] * 10 + [_i] * 10 + [_vp] * 8 + [_i, _i, _vp]),
     "lss_region_pipeline_ok": (_i, [_i] * 9),
+    "lss_lift_splat_from_heads": (_i, [_vp] * 9 + [_i] * 9 + [_vp] * 6 + [_i, _vp]),
     "lss_head_ce_workspace_bytes": (_sz, [_i]),
     "lss_head_ce_fwd": (_i, [_vp] * 5 + [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp]),
     "lss_head_ce_bwd": (_i, [_vp] * 5 + [ctypes.c_longlong, _i, _i] + [_vp] * 7),

@@ -629,6 +629,62 @@ int lss_region_depthnet_voxels(const float* frustum, const float* inv_post_rots,
                               D, fH, fW, Cin, C, X, Y, Z, voxel, nullptr, depth, feat, stream, &plan);
 }
 
+// Region pipeline for depth / context tensors that OTHER kernels produced (the vovnet depth heads + CamEncodeV2, ref
+// src/model_vovnet_transformer.py:22-122): launch 1 without the depthnet.  Blocks [0, n2): max |finite feature| of one
+// 16-pixel tile of a camera image (the slots the depthnet workgroups fill on the fused path: the fill kernel reduces
+// them to the scale of the fixed-point splat); blocks [n2, ...): the geometry with its LDS region histograms.
+__global__ __launch_bounds__(256) void absmax_and_voxels_kernel(FusedK2K3Args a, int C) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int id = blockIdx.x;
+  if (id < a.n2) {
+    const int tile = id % a.gx2, bn = id / a.gx2, pix0 = tile * lss_depthnet::PIX;
+    const int npix = min(lss_depthnet::PIX, a.HW - pix0);
+    const float* f = a.feat + ((size_t)bn * a.HW + pix0) * C;
+    float amax = 0.f;
+    for (int e = threadIdx.x; e < npix * C; e += 256) {
+      const float av = fabsf(f[e]);
+      amax = fmaxf(amax, av <= 3.0e38f ? av : 0.f);
+    }
+    amax = lss_wave_max(amax);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) a.rg.wg_absmax[id] = fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]));
+  } else {
+    const int k = id - a.n2;
+    const CalPtr calp = {a.inv_post_rots, a.post_trans, a.combine, a.trans};
+    points_to_voxels_body(a.frustum, calp, a.dx, a.bx, a.Ncam, a.DHW, a.X, a.Y, a.Z, a.voxel, nullptr, nullptr, k % a.gx3,
+                          k / a.gx3, reinterpret_cast<int*>(lds), &a.rg);
+  }
+}
+
+int lss_region_voxels_absmax(const float* frustum, const float* inv_post_rots, const float* post_trans,
+                             const float* combine, const float* trans, const float* dx, const float* bx,
+                             const float* feat, int B, int N, int D, int fH, int fW, int C, int X, int Y, int Z,
+                             int32_t* voxel, const LssRegionPlan& plan, void* stream) {
+  LSS_CHECK_PTR(frustum); LSS_CHECK_PTR(inv_post_rots); LSS_CHECK_PTR(post_trans); LSS_CHECK_PTR(combine);
+  LSS_CHECK_PTR(trans); LSS_CHECK_PTR(dx); LSS_CHECK_PTR(bx); LSS_CHECK_PTR(feat); LSS_CHECK_PTR(voxel);
+  const long long DHW = (long long)D * fH * fW;
+  if (DHW * B * N >= (1LL << 31) || B * N > 65535) return LSS_E_SHAPE;
+  FusedK2K3Args a = {};
+  a.feat = const_cast<float*>(feat); a.HW = fH * fW; a.D = D; a.C = C;
+  a.gx2 = lss_cdiv(a.HW, lss_depthnet::PIX);
+  a.n2 = a.gx2 * B * N;
+  if (plan.n2 != a.n2 || plan.rps != plan.nRx * plan.nRy) return LSS_E_WORKSPACE;
+  a.frustum = frustum; a.inv_post_rots = inv_post_rots; a.post_trans = post_trans; a.combine = combine;
+  a.trans = trans; a.dx = dx; a.bx = bx; a.Ncam = N; a.DHW = (int)DHW; a.X = X; a.Y = Y; a.Z = Z;
+  a.voxel = voxel; a.vox_count = nullptr; a.use_regions = 1;
+  a.rg.region_count = plan.region_count; a.rg.region_cursor = plan.region_cursor; a.rg.region_start = plan.region_start;
+  a.rg.wg_absmax = plan.wg_absmax; a.rg.nRy = plan.nRy; a.rg.rps = plan.rps;
+  a.gx3 = lss_cdiv(DHW, 256);
+  const long long nblk = (long long)a.n2 + (long long)a.gx3 * B * N;
+  if (nblk >= (1LL << 31)) return LSS_E_SHAPE;
+  size_t lds_bytes = (size_t)plan.rps * sizeof(int);
+  if (lds_bytes < 64) lds_bytes = 64;
+  if (lds_bytes > 64 * 1024) return LSS_E_SHAPE;
+  hipLaunchKernelGGL(absmax_and_voxels_kernel, dim3((unsigned)nblk), dim3(256), lds_bytes, lss_stream(stream), a, C);
+  return lss_launch_status();
+}
+
 int lss_region_fill(const int32_t* voxel, const float* depth, int B, int N, int D, int HW, int X, int Y, int Z,
                     const LssRegionPlan& plan, int32_t* entries, void* stream) {
   LSS_CHECK_PTR(voxel); LSS_CHECK_PTR(depth); LSS_CHECK_PTR(entries);

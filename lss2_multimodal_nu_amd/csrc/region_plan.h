@@ -22,6 +22,11 @@ int lss_region_depthnet_voxels(const float* frustum, const float* inv_post_rots,
                                const float* bx, const float* x, const float* w, const float* bias, int B, int N, int D,
                                int fH, int fW, int Cin, int C, int X, int Y, int Z, int32_t* voxel, float* depth,
                                float* feat, const LssRegionPlan& plan, void* stream);
+// launch 1 without the depthnet: depth / context come from other kernels (vovnet heads); feat (B*N*fH*fW, C) fp32
+int lss_region_voxels_absmax(const float* frustum, const float* inv_post_rots, const float* post_trans,
+                             const float* combine, const float* trans, const float* dx, const float* bx,
+                             const float* feat, int B, int N, int D, int fH, int fW, int C, int X, int Y, int Z,
+                             int32_t* voxel, const LssRegionPlan& plan, void* stream);
 // launch 2
 int lss_region_fill(const int32_t* voxel, const float* depth, int B, int N, int D, int HW, int X, int Y, int Z,
                     const LssRegionPlan& plan, int32_t* entries, void* stream);

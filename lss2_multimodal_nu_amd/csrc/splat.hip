@@ -753,6 +753,39 @@ static int lift_splat_forward_impl(const float* frustum, const float* inv_post_r
   return lss_lift_splat_fwd(feat, vox_list, entries, B, N, D, fH, fW, C, X, Y, Z, bev, layout, stream);
 }
 
+// Lift-splat of depth / context tensors produced elsewhere (vovnet depth heads, CamEncodeV2): geometry + bucketing +
+// splat behind one call.  Region pipeline when the problem fits it (C = 128 included), else K3 -> K4 -> K5.
+extern "C" int lss_lift_splat_from_heads(const float* frustum, const float* inv_post_rots, const float* post_trans,
+                                         const float* combine, const float* trans, const float* dx, const float* bx,
+                                         const float* depth, const float* feat, int B, int N, int D, int fH, int fW,
+                                         int C, int X, int Y, int Z, int32_t* voxel, int32_t* vox_count,
+                                         int32_t* vox_list, int32_t* entries, int32_t* cursor, void* bev, int layout,
+                                         void* stream) {
+  LSS_CHECK_PTR(depth); LSS_CHECK_PTR(feat); LSS_CHECK_PTR(voxel); LSS_CHECK_PTR(vox_count); LSS_CHECK_PTR(vox_list);
+  LSS_CHECK_PTR(entries); LSS_CHECK_PTR(cursor); LSS_CHECK_PTR(bev);
+  LSS_CHECK_POS(B); LSS_CHECK_POS(N); LSS_CHECK_POS(D); LSS_CHECK_POS(fH); LSS_CHECK_POS(fW);
+  LSS_CHECK_POS(X); LSS_CHECK_POS(Y); LSS_CHECK_POS(Z);
+  if (C != 64 && C != 128) return LSS_E_SHAPE;
+  if (layout < 0 || layout > 2) return LSS_E_LAYOUT;
+  int rc;
+  LssRegionPlan rp;
+  if ((reinterpret_cast<uintptr_t>(bev) & 15) == 0 && region_plan_for(B, N, D, fH, fW, C, X, Y, Z, vox_count, vox_list, &rp)) {
+    rc = lss_region_voxels_absmax(frustum, inv_post_rots, post_trans, combine, trans, dx, bx, feat, B, N, D, fH, fW, C, X,
+                                  Y, Z, voxel, rp, stream);
+    if (rc) return rc;
+    rc = lss_region_fill(voxel, depth, B, N, D, fH * fW, X, Y, Z, rp, entries, stream);
+    if (rc) return rc;
+    return region_splat_launch(feat, entries, rp, B, C, X, Y, Z, bev, layout, lss_stream(stream));
+  }
+  rc = lss_points_to_voxels(frustum, inv_post_rots, post_trans, combine, trans, dx, bx, B, N, D, fH, fW, X, Y, Z, voxel,
+                            vox_count, nullptr, stream);
+  if (rc) return rc;
+  rc = lss_bucket_points(voxel, depth, B * N * D * fH * fW, D, fH * fW, B * X * Y * Z, vox_count, vox_list, entries,
+                         cursor, stream);
+  if (rc) return rc;
+  return lss_lift_splat_fwd(feat, vox_list, entries, B, N, D, fH, fW, C, X, Y, Z, bev, layout, stream);
+}
+
 extern "C" int lss_lift_splat_forward(const float* frustum, const float* inv_post_rots,
                                       const float* post_trans, const float* combine, const float* trans,
                                       const float* dx, const float* bx, const float* x, const float* w,

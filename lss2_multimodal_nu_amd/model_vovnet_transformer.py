@@ -313,11 +313,17 @@ class VoVNetBEVTransformer(_LiftSplatMixin, nn.Module):
             cam = self.cam_encode(c3, depth).view(B, Ncam, self.C, self.D, fH, fW).permute(0, 1, 3, 4, 5, 2)
             return self.voxel_pooling(self.get_geometry(rots, trans, intrins, post_rots, post_trans), cam)
         with ops.region("lift_splat_level"):
-            ws, _ = self._index_points(rots, trans, intrins, post_rots, post_trans)
-            with _histogram_guard(ws):  # a failure between K3 and K4 must not leave the counters dirty
-                depth, feat = self.depth_net.depth_and_context(c3, c4, self.cam_encode)
-                ops.bucket_points(ws, depth, self.D, fH * fW)
-            return ops.lift_splat_fwd(feat, ws, (B, Ncam, self.D, fH, fW, self.C), self._nx_ints(), layout)
+            # depth heads + CamEncodeV2 (K2v), then geometry + bucketing + splat behind one native call: the
+            # region-bucketed pipeline at C = 128 (LDS region histograms, fixed-point region splat)
+            dev = self.frustum.device
+            nx = self._nx_ints()
+            inv_pr, comb, ptr, trn = self._device_calib(dev, rots, trans, intrins, post_rots, post_trans)
+            ws = self._workspace(B * Ncam * self.D * fH * fW, B * nx[0] * nx[1] * nx[2], dev)
+            depth, feat = self.depth_net.depth_and_context(c3, c4, self.cam_encode)
+            with _histogram_guard(ws):  # a failed call must not leave the zero-between-calls words dirty
+                return ops.lift_splat_from_heads(self.frustum.detach(), inv_pr, ptr, comb, trn, self.dx.detach(),
+                                                 self.bx.detach(), depth, feat, ws, (B, Ncam, self.D, fH, fW, self.C),
+                                                 nx, layout)
 
     def forward(self, imgs, rots, trans, intrins, post_rots, post_trans):
         """imgs: (B*N,3,H,W) / (B,N,3,H,W) camera images for a real trunk, or the

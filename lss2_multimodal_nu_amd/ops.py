@@ -398,6 +398,38 @@ def linear_res_ln(x, w, bias, residual, ln=None):
 HOSTCAL_MAX_CAMS = 36
 
 
+def lift_splat_from_heads(frustum, inv_post_rots, post_trans, combine, trans, dx, bx, depth, feat, ws, dims, nx,
+                          layout=BEV_NCHW_F32):
+    """Geometry + bucketing + splat of depth (B*N, D, fH, fW) / context (B*N, fH, fW, C) tensors that other kernels
+    produced (the vovnet depth heads + CamEncodeV2) with ONE native call; region-bucketed pipeline when the problem
+    fits it.  Returns the BEV grid (logical (B, Z*C, X, Y))."""
+    B, Ncam, D, fH, fW, C = dims
+    X, Y, Z = nx
+    for t, name, shp in ((frustum, "frustum", (D, fH, fW, 3)), (inv_post_rots, "inv_post_rots", (B, Ncam, 3, 3)),
+                         (combine, "combine", (B, Ncam, 3, 3)), (post_trans, "post_trans", (B, Ncam, 3)),
+                         (trans, "trans", (B, Ncam, 3)), (dx, "dx", (3,)), (bx, "bx", (3,)),
+                         (depth, "depth", (B * Ncam, D, fH, fW))):
+        _f32c(t, name, shp)
+    _f32c(feat, "feat")
+    if feat.numel() != B * Ncam * fH * fW * C or C not in (64, 128):
+        raise ValueError("feat must hold (B*N*fH*fW, C) context rows with C in (64, 128)")
+    if ws.P != B * Ncam * D * fH * fW or ws.nvox != B * X * Y * Z:
+        raise ValueError("workspace does not match dims")
+    dev = feat.device
+    if layout == BEV_NCHW_F32:
+        bev = torch.empty(B, Z * C, X, Y, dtype=torch.float32, device=dev)
+        out = bev
+    else:
+        bev = torch.empty(B, X, Y, Z * C, dtype=torch.float32 if layout == BEV_NHWC_F32 else torch.bfloat16, device=dev)
+        out = bev.permute(0, 3, 1, 2)
+    N.check(N.lib().lss_lift_splat_from_heads(
+        N.ptr(frustum), N.ptr(inv_post_rots), N.ptr(post_trans), N.ptr(combine), N.ptr(trans), N.ptr(dx), N.ptr(bx),
+        N.ptr(depth), N.ptr(feat), B, Ncam, D, fH, fW, C, X, Y, Z, N.ptr(ws.voxel), N.ptr(ws.vox_count),
+        N.ptr(ws.vox_list), N.ptr(ws.entries), N.ptr(ws.cursor), N.ptr(bev), layout, N.stream()),
+        "lss_lift_splat_from_heads")
+    return out
+
+
 def lift_splat_forward_hostcal(frustum, calib_host, dx, bx, x, weight, bias, ws, dims, nx, layout=BEV_NCHW_F32):
     """lift_splat_forward with the calibration as ONE CPU fp32 buffer of B*N*24 floats
     ([inv_post_rots | combine | post_trans | trans] = data.CalibrationPack.buffer): it is read during the
