@@ -34,7 +34,7 @@ def last_json_line(path):
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
     dst = os.path.join(ROOT, "profiles")
     w = lambda name, text: open(os.path.join(dst, "%s_%s" % (rnd, name)), "w").write(text)
@@ -64,8 +64,19 @@ def main():
                 "--no-cpu-baseline --no-train\n# mean per dispatch (tools/pmc_sq_summary.py); MFMA_util = "
                 "SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs)\n")
         w("conv_pmc_sq.txt", head + run_tool("pmc_sq_summary.py", sq, sqkt))
+    sq, sqkt = find(os.path.join(src, "sq_ring"), "*counter_collection.csv"), find(os.path.join(src, "sq_ring"), "*kernel_trace.csv")
+    if sq and sqkt:
+        head = ("# rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
+                "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- python tools/bench_ring.py --rounds 2 --iters 3\n"
+                "# the three big convs on the tile kernel (conv_lds_kernel) and on the ring kernel (conv_ring_kernel), mean per "
+                "dispatch; MFMA_util = SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs)\n")
+        w("ring_pmc_sq.txt", head + "\n".join(ln for ln in run_tool("pmc_sq_summary.py", sq, sqkt).splitlines()
+                                               if "conv_" in ln or ln.startswith("kernel")) + "\n")
     for tag, out in (("bk_conv.txt", "conv_microbench.txt"), ("bk_stamps.txt", "conv_phase_stamps.txt"),
-                     ("bk_l1.txt", "l1_microbench.txt"), ("l1_stamps.txt", "l1_stamps.txt")):
+                     ("bk_l1.txt", "l1_microbench.txt"), ("l1_stamps.txt", "l1_stamps.txt"),
+                     ("ring_microbench.txt", "ring_microbench.txt"), ("ring_wait_stats.txt", "ring_wait_stats.txt"),
+                     ("ring_microbench_noblend.txt", "ring_microbench_noblend.txt"),
+                     ("ring_microbench_nowdma.txt", "ring_microbench_nowdma.txt")):
         p = os.path.join(src, tag)
         if os.path.exists(p):
             w(out, "".join(ln for ln in open(p) if "amdgpu.ids" not in ln))
