@@ -664,20 +664,31 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
         a.y, 0, a.wt ? (int)((size_t)a.B * a.Hin * a.Win * a.Cout * 2) : 0, 0x00020000);
+    // Lane (q, n) holds 32 B of pixel n as two 16-B halves; stored as they lie, one instruction would write 16 B of
+    // every 32-B sector and the write-through path sends each partial sector to HBM on its own (WRITE_SIZE = 2 x the
+    // output, profiles/r03_hbm_traffic.json before this).  Two row swaps (v_permlane16_swap, v_permlane32_swap) hand
+    // the q lanes of a pixel consecutive 16-B pieces: one instruction = 64 contiguous bytes per pixel.
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    const int chs = T.nb * 128 + cg * 64 + kq * 8;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int ox = my_ox0 + j * 4 + (n & 3);
+      u32x4 ox_[2];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const unsigned lo = rk_pack_bf2(acc[j][d >> 1][(d & 1) * 2], acc[j][d >> 1][(d & 1) * 2 + 1]);
+        const unsigned hi = rk_pack_bf2(acc[j][2 + (d >> 1)][(d & 1) * 2], acc[j][2 + (d >> 1)][(d & 1) * 2 + 1]);
+        const u32x2 r = __builtin_amdgcn_permlane16_swap(lo, hi, false, false);      // rows: [0l 0h 2l 2h] [1l 1h 3l 3h]
+        const u32x2 t = __builtin_amdgcn_permlane32_swap(r[0], r[1], false, false);  //       [0l 0h 1l 1h] [2l 2h 3l 3h]
+        ox_[0][d] = t[0];
+        ox_[1][d] = t[1];
+      }
       if (!my_ok || oy >= a.Hin || ox >= a.Win) continue;
-      const size_t o = (((size_t)my_b * a.Hin + oy) * a.Win + ox) * a.Cout + ch0;
+      const size_t o = (((size_t)my_b * a.Hin + oy) * a.Win + ox) * a.Cout + chs;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        u32x4 ov;
-        ov[0] = rk_pack_bf2(acc[j][2 * hf][0], acc[j][2 * hf][1]);
-        ov[1] = rk_pack_bf2(acc[j][2 * hf][2], acc[j][2 * hf][3]);
-        ov[2] = rk_pack_bf2(acc[j][2 * hf + 1][0], acc[j][2 * hf + 1][1]);
-        ov[3] = rk_pack_bf2(acc[j][2 * hf + 1][2], acc[j][2 * hf + 1][3]);
-        if (a.wt) __builtin_amdgcn_raw_buffer_store_b128(ov, yrsrc, (int)((o + hf * 8) * 2), 0, 16);  // write-through
-        else *reinterpret_cast<u32x4*>(a.y + o + hf * 8) = ov;
+        if (a.wt) __builtin_amdgcn_raw_buffer_store_b128(ox_[hf], yrsrc, (int)((o + hf * 32) * 2), 0, 16);  // write-through
+        else *reinterpret_cast<u32x4*>(a.y + o + hf * 32) = ox_[hf];
       }
     }
   } else {

@@ -595,3 +595,84 @@ def test_forward_loss_fp32_equals_forward_plus_simple_loss(report):
         checked += 1
     report("forward_loss fp32: max grad rel-L2", worst)
     assert checked > 40
+
+
+def test_training_step_vs_cpu_oracle_autograd(report):
+    """one full BevEncode training step (bf16 autocast: native conv + BatchNorm(train) units, fused 1x1
+    head + weighted cross-entropy) pinned against the CPU oracle's autograd (`oracle.bev_oracle.bev_encode(training=
+    True)`, fp32, ref src/modules.py:94-130 + src/tools.py:221-231): the loss, EVERY parameter gradient, the updated
+    BatchNorm running statistics - and the step repeated on the same inputs must reproduce itself."""
+    torch.manual_seed(31)
+    B = 1
+    be = L.BevEncode(64, 4, precision="bf16")
+    randomize_bn(be)
+    with torch.no_grad():  # zero_init_residual would hide half the net from the gradient check
+        for blk in list(be.layer1) + list(be.layer2) + list(be.layer3):
+            blk.bn2.weight.fill_(0.7)
+    sd0 = {k: v.clone() for k, v in be.state_dict().items()}
+    x = torch.randn(B, 64, 200, 200)
+    tgt = torch.randint(0, 4, (B, 200, 200))
+    cw = torch.tensor([1.0, 10.0, 5.0, 10.0])
+
+    def gpu_step(bf16=True):
+        m = L.BevEncode(64, 4, precision="bf16" if bf16 else "fp32")
+        m.load_state_dict(sd0)
+        m = m.cuda().train()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            y = m.features(x.cuda())
+            loss = L.tools.head_weighted_cross_entropy(y, m.up2[4], tgt.cuda(), cw.cuda())
+        loss.backward()
+        return m, loss
+
+    m, loss = gpu_step()
+    # the oracle: the same step in fp32 on the CPU (functional form over a state dict whose tensors require grad)
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "num_batches" not in k)
+          for k, v in sd0.items()}
+    stats = {}
+    ref_logits = bo.bev_encode(x, sd, training=True, stats_out=stats)
+    ref_loss = torch.nn.functional.cross_entropy(ref_logits, tgt, weight=cw)
+    ref_loss.backward()
+    e_loss = report("train_step loss rel err (bf16 GPU vs fp32 CPU oracle)", abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)))
+    assert e_loss < 1e-2
+    worst, n = 1.0, 0
+    for name, p in m.named_parameters():
+        g_ref = sd[name].grad
+        assert (p.grad is None) == (g_ref is None), name
+        if g_ref is None or float(g_ref.norm()) == 0:
+            continue
+        a, b = p.grad.float().cpu().flatten(), g_ref.flatten()
+        cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+        ratio = float(a.norm() / b.norm())
+        worst = min(worst, cos)
+        # bf16 activations and gradients through 19 layers against fp32: lowest on the 7x7 stem (the longest backward
+        # chain; measured 0.960 there, >= 0.97 elsewhere); the fp32 step below pins the structure tightly
+        assert cos > 0.95 and abs(ratio - 1) < 0.1, (name, cos, ratio)
+        n += 1
+    report("train_step min grad cosine vs oracle (bf16)", worst)
+    assert n >= 50
+    # the same step in fp32 on the GPU: what is left against the oracle is summation order only
+    m32, loss32 = gpu_step(bf16=False)
+    assert abs(float(loss32) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+    worst32 = 1.0
+    for name, p in m32.named_parameters():
+        g_ref = sd[name].grad
+        if g_ref is None or float(g_ref.norm()) == 0:
+            continue
+        a, b = p.grad.float().cpu().flatten(), g_ref.flatten()
+        cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+        worst32 = min(worst32, cos)
+        assert cos > 0.9995 and abs(float(a.norm() / b.norm()) - 1) < 5e-3, (name, cos)
+    report("train_step min grad cosine vs oracle (fp32)", worst32)
+    # running statistics after the step (momentum update with the batch statistics)
+    for name, buf in m.named_buffers():
+        if name.endswith("running_mean") or name.endswith("running_var"):
+            ref = stats.get(name)
+            if ref is not None:
+                assert torch.allclose(buf.float().cpu(), ref, rtol=3e-2, atol=3e-2), name
+    # the same step again: same loss and gradients bit for bit (no unordered float reduction on the native path;
+    # the library convs of the stride-2 / 1x1 / 7x7 layers are the ones that may differ, reported not asserted)
+    m2, loss2 = gpu_step()
+    same = sum(int(torch.equal(p.grad, q.grad)) for p, q in zip(m.parameters(), m2.parameters()) if p.grad is not None)
+    total = sum(1 for p in m.parameters() if p.grad is not None)
+    report("train_step bit-identical gradient tensors (of %d)" % total, same)
+    assert abs(float(loss) - float(loss2)) <= 1e-6 * abs(float(loss))
