@@ -431,15 +431,25 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
             const unsigned char* p00 = smem + L::SRC + (it / 9) * RK_SRC_STRIP + (g_off[k] & 0xfff0);
             const int dx = (g_off[k] & 1) ? 4 * 16 : 0, dy = (g_off[k] & 2) ? RK_SRC_W * 4 * 16 : 0;
             q[0] = *reinterpret_cast<const uint4*>(p00);
+#if defined(RK_DIAG_ONEREAD)  // timing-only: one corner read, the full arithmetic
+            q[1] = q[0]; q[2] = q[0]; q[3] = q[0];
+            asm volatile("" : "+v"(q[1].x), "+v"(q[2].x), "+v"(q[3].x));
+#else
             q[1] = *reinterpret_cast<const uint4*>(p00 + dx);
             q[2] = *reinterpret_cast<const uint4*>(p00 + dy);
             q[3] = *reinterpret_cast<const uint4*>(p00 + dy + dx);
+#endif
           };
           auto finish = [&](int k, const uint4* q) {
             uint4 v = make_uint4(0, 0, 0, 0);
 #ifndef RK_DIAG_NOBLEND  // timing-only build: the upsampled patch stays zero
+#if defined(RK_DIAG_READSONLY)  // timing-only: the four corner reads, no arithmetic
+            v.x = q[0].x ^ q[1].x ^ q[2].x ^ q[3].x; v.y = q[0].y ^ q[1].y ^ q[2].y ^ q[3].y;
+            v.z = q[0].z ^ q[1].z ^ q[2].z ^ q[3].z; v.w = q[0].w ^ q[1].w ^ q[2].w ^ q[3].w;
+#else
             v = rk_blend(q[0], q[1], q[2], q[3], (float)(g_w[k] & 0xffff) * (1.f / 65536.f),
                          (float)(g_w[k] >> 16) * (1.f / 65536.f));
+#endif
             const bool in = (g_off[k] & 4) != 0;
             v.x = in ? v.x : 0u; v.y = in ? v.y : 0u; v.z = in ? v.z : 0u; v.w = in ? v.w : 0u;
 #endif
