@@ -284,6 +284,10 @@ int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packed,
 int lss_conv2d_ring_ok(int B, int H, int W, int Cx, int C2, int up, int Cout, int head_n);
 size_t lss_conv2d_ring_packed_weight_bytes(int Cout, int Cin);
 int lss_conv2d_pack_weights_ring(const float* w_oihw, int Cout, int Cin, void* w_packed, void* stream);
+/* The same layout for the conv that maps dY (Cout channels) to dX (Cin channels) of a 3x3 / s1 / p1 conv with weight
+ * w_oihw [Cout][Cin][3][3] (the autograd node ConvolutionBackward of ref src/modules.py:22-27 run by train.py:61):
+ * lss_conv2d_fwd(dy, ..., Cx = Cout, Cout = Cin, relu = LSS_W_RING) then computes the input gradient. */
+int lss_conv2d_pack_weights_ring_dgrad(const float* w_oihw, int Cout, int Cin, void* w_packed, void* stream);
 /* flag waits of the ring kernel that hit their bound since load (must be 0; synchronises the device) */
 int lss_conv2d_ring_timeouts(void);
 

@@ -299,15 +299,24 @@ extern "C" int lss_bn_train_bwd(const void* dy, const void* y, const void* z, lo
 // -> (+residual) -> ReLU, forward and backward, as ONE host call each.  The training step is
 // framework-bound (a Python autograd node costs more than most of these kernels run), so the
 // host side hands over every pointer once and the launches are chained here.
+// LSS_CONV_RING=0: the tile kernel everywhere (developer A/B, same switch as ops.conv_ring_ok)
+static bool train_ring_enabled() {
+  const char* e = getenv("LSS_CONV_RING");
+  return e == nullptr || atoi(e) != 0;
+}
+
 extern "C" int lss_conv_bn_act_train_fwd(const void* x1, const void* x2, const float* w_oihw, const float* gamma,
                                          const float* beta, const void* residual, float* running_mean,
                                          float* running_var, void* w_packed, void* z, void* y, float* save_mean,
                                          float* save_invstd, void* bn_workspace, int B, int H, int W, int Cx, int C2,
                                          int up, int Cout, float momentum, float eps, int relu, void* stream) {
-  int rc = lss_conv2d_pack_weights(w_oihw, Cout, Cx + C2, 3, 3, LSS_DT_BF16, w_packed, stream);
+  // the big layers run on the loader / consumer ring kernel (conv_ring.hip), like the inference path
+  const bool ring = train_ring_enabled() && lss_conv2d_ring_ok(B, H, W, Cx, C2, up, Cout, 0);
+  int rc = ring ? lss_conv2d_pack_weights_ring(w_oihw, Cout, Cx + C2, w_packed, stream)
+                : lss_conv2d_pack_weights(w_oihw, Cout, Cx + C2, 3, 3, LSS_DT_BF16, w_packed, stream);
   if (rc != 0) return rc;
   rc = lss_conv2d_fwd(x1, x2, w_packed, nullptr, nullptr, nullptr, z, nullptr, B, H, W, Cx, C2, up, Cout, 3, 3, 1, 1,
-                      LSS_ACT_NONE, LSS_DT_BF16, stream);
+                      LSS_ACT_NONE | (ring ? LSS_W_RING : 0), LSS_DT_BF16, stream);
   if (rc != 0) return rc;
   const long long M = (long long)B * (H * up) * (W * up);
   return lss_bn_train_fwd(z, residual, M, Cout, gamma, beta, running_mean, running_var, momentum, eps, relu,
@@ -328,10 +337,12 @@ extern "C" int lss_conv_bn_act_train_bwd(const void* dy, const void* y, const vo
   if (rc != 0) return rc;
   if (gcat != nullptr) {  // input gradient(s): dgrad conv over the (concatenated, upsampled) input
     LSS_CHECK_PTR(w_dgrad);
-    rc = lss_conv2d_pack_weights_dgrad(w_oihw, Cout, Ct, 3, 3, LSS_DT_BF16, w_dgrad, stream);
+    const bool ring = train_ring_enabled() && lss_conv2d_ring_ok(B, Hh, Wh, Cout, 0, 1, Ct, 0);
+    rc = ring ? lss_conv2d_pack_weights_ring_dgrad(w_oihw, Cout, Ct, w_dgrad, stream)
+              : lss_conv2d_pack_weights_dgrad(w_oihw, Cout, Ct, 3, 3, LSS_DT_BF16, w_dgrad, stream);
     if (rc != 0) return rc;
     rc = lss_conv2d_fwd(dz, nullptr, w_dgrad, nullptr, nullptr, nullptr, gcat, nullptr, B, Hh, Wh, Cout, 0, 1, Ct, 3, 3,
-                        1, 1, LSS_ACT_NONE, LSS_DT_BF16, stream);
+                        1, 1, LSS_ACT_NONE | (ring ? LSS_W_RING : 0), LSS_DT_BF16, stream);
     if (rc != 0) return rc;
     if (g1 != nullptr) {
       rc = lss_upsample_bwd_nhwc(gcat, B, H, W, Cx, Ct, C2, up, g1, stream);

@@ -760,6 +760,9 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
 
 // OIHW fp32 -> ring layout bf16: slab (nb, chunk, tap) = 8 KiB, piece (cg, t, l) at ((cg*4+t)*64+l)*16 B holds
 // W[co = nb*128 + cg*64 + ((l&15)>>2)*16 + 4t + (l&3)][ci = chunk*32 + (l>>4)*8 .. +8][tap]
+// DGRAD: the conv that maps dY to dX - its output channels are w's INPUT channels and tap (ky, kx) takes w's tap
+// (2 - ky, 2 - kx); Cout / Cin below are THAT conv's (w is [Cin][Cout][3][3] then).
+template <bool DGRAD>
 __global__ void pack_weights_ring_kernel(const float* __restrict__ w, int Cout, int Cin, unsigned short* __restrict__ out) {
   const size_t n = (size_t)Cout * Cin * 9;
   const int nch = Cin / RK_KC;
@@ -774,7 +777,7 @@ __global__ void pack_weights_ring_kernel(const float* __restrict__ w, int Cout, 
     const int nb = r / nch;
     const int co = nb * 128 + cg * 64 + ((l & 15) >> 2) * 16 + 4 * t + (l & 3);
     const int ci = chunk * RK_KC + (l >> 4) * 8 + j;
-    out[e] = lss_f2bf(w[((size_t)co * Cin + ci) * 9 + tap]);
+    out[e] = lss_f2bf(DGRAD ? w[((size_t)ci * Cout + co) * 9 + (8 - tap)] : w[((size_t)co * Cin + ci) * 9 + tap]);
   }
 }
 
@@ -820,7 +823,19 @@ extern "C" int lss_conv2d_pack_weights_ring(const float* w_oihw, int Cout, int C
   if (lss_conv2d_ring_packed_weight_bytes(Cout, Cin) == 0) return LSS_E_SHAPE;
   const size_t n = (size_t)Cout * Cin * 9;
   const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-  hipLaunchKernelGGL(pack_weights_ring_kernel, dim3(grid), dim3(256), 0, lss_stream(stream), w_oihw, Cout, Cin,
+  hipLaunchKernelGGL(pack_weights_ring_kernel<false>, dim3(grid), dim3(256), 0, lss_stream(stream), w_oihw, Cout, Cin,
+                     reinterpret_cast<unsigned short*>(w_packed));
+  return lss_launch_status();
+}
+
+// Ring-packed weight of the conv that maps dY (Cout channels) to dX (Cin channels) of a 3x3 / s1 / p1 conv with
+// weight w_oihw [Cout][Cin][3][3]: use with lss_conv2d_fwd(dy, ..., Cx = Cout, Cout = Cin, LSS_W_RING).
+extern "C" int lss_conv2d_pack_weights_ring_dgrad(const float* w_oihw, int Cout, int Cin, void* w_packed, void* stream) {
+  LSS_CHECK_PTR(w_oihw); LSS_CHECK_PTR(w_packed);
+  if (lss_conv2d_ring_packed_weight_bytes(Cin, Cout) == 0) return LSS_E_SHAPE;
+  const size_t n = (size_t)Cout * Cin * 9;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(pack_weights_ring_kernel<true>, dim3(grid), dim3(256), 0, lss_stream(stream), w_oihw, Cin, Cout,
                      reinterpret_cast<unsigned short*>(w_packed));
   return lss_launch_status();
 }

@@ -598,6 +598,19 @@ def pack_conv_weight_ring(w_oihw):
     return RingWeight(out, Cout, Cin)
 
 
+def pack_conv_weight_ring_dgrad(w_oihw):
+    """OIHW fp32 (3x3) -> RingWeight of the conv that maps dY (Cout channels) to dX (Cin channels)."""
+    Cout, Cin, KH, KW = w_oihw.shape
+    _f32c(w_oihw, "conv weight")
+    nbytes = N.lib().lss_conv2d_ring_packed_weight_bytes(Cin, Cout)
+    if (KH, KW) != (3, 3) or nbytes == 0:
+        raise ValueError("ring dgrad weights: 3x3, Cin % 128 == 0, Cout % 32 == 0 (got %s)" % (tuple(w_oihw.shape),))
+    out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w_oihw.device)
+    N.check(N.lib().lss_conv2d_pack_weights_ring_dgrad(N.ptr(w_oihw), Cout, Cin, N.ptr(out), N.stream()),
+            "lss_conv2d_pack_weights_ring_dgrad")
+    return RingWeight(out, Cin, Cout)
+
+
 def conv2d_nhwc(x, w_packed, ksize, stride, pad, scale=None, shift=None, residual=None, relu=False,
                 x2=None, up=1, stats=None, dt=DT_BF16, tag="conv2d_fwd", out_f32=False, head_major=False):
     """K8.  x (B,H,W,Cx) NHWC in `dt`; x2 (B,H*up,W*up,C2) optional skip tensor

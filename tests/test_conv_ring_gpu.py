@@ -93,3 +93,26 @@ def test_ring_weights_are_rejected_where_the_kernel_has_no_case(ops):
         ops.conv2d_nhwc(x, wr, (3, 3), 1, 1, None, None, None, True, None, 1, None, 1)
     with pytest.raises(ValueError):
         ops.pack_conv_weight_ring(torch.randn(96, 64, 3, 3).cuda())
+
+
+@pytest.mark.parametrize("cfg", [(4, 100, 100, 256, 256), (2, 96, 120, 128, 256), (6, 61, 83, 64, 128)])
+def test_ring_dgrad_vs_autograd(ops, report, cfg):
+    """Input gradient of a 3x3 / s1 / p1 conv = the ring kernel on dY with the dgrad-packed weight
+    (lss_conv2d_pack_weights_ring_dgrad), against torch's CPU autograd on the same bf16-rounded operands
+    (the ConvolutionBackward nodes of ref src/modules.py:22-27 under train.py:61)."""
+    B, H, W, Cout, Cin = cfg     # forward conv: Cin -> Cout; dgrad: Cout channels in, Cin channels out
+    assert ops.conv_ring_ok(B, H, W, Cout, 0, 1, Cin, 0)
+    gen = torch.Generator().manual_seed(B + H + W + Cout + Cin)
+    w = _q(torch.randn(Cout, Cin, 3, 3, generator=gen) * (Cin * 9) ** -0.5)
+    dy = _q(torch.randn(B, Cout, H, W, generator=gen))
+    x = torch.zeros(B, Cin, H, W, requires_grad=True)
+    torch.nn.functional.conv2d(x, w, None, padding=1).backward(dy)
+    ref = x.grad
+    wd = ops.pack_conv_weight_ring_dgrad(w.cuda())
+    before = ops.N.lib().lss_conv2d_ring_timeouts()
+    g = ops.conv2d_nhwc(ops.nchw_to_nhwc(dy.cuda(), 1), wd, (3, 3), 1, 1, None, None, None, False, None, 1, None, 1)
+    out = ops.nhwc_to_nchw(g, 1).cpu()
+    assert ops.N.lib().lss_conv2d_ring_timeouts() == before
+    tag = "x".join(str(c) for c in cfg)
+    assert report("k8r_dgrad_max_rel_" + tag, (out - ref).abs().max() / ref.abs().max()) <= BF16_OUT_TOL
+    assert report("k8r_dgrad_rel_l2_" + tag, (out - ref).norm() / ref.norm()) <= BF16_OUT_TOL / 3
