@@ -304,12 +304,17 @@ int lss_conv2d_ring_timeouts(void);
  *   workspace: lss_conv2d_wgrad_workspace_bytes bytes, 256-B aligned (channel-major copies of
  *   both operands + fp32 split-K partials); dw_oihw (Cout,Cin,3,3) fp32, fully overwritten.
  *   Cin % 8 == 0, Cout % 8 == 0.  Fixed summation order: bit-reproducible.
+ *   Shapes with Cin % 64 == 0, Cout % 64 == 0 and 8 <= W <= 224 run on K9w (csrc/conv_wgrad.hip): one kernel that
+ *   reads both NHWC tensors as they lie and transposes the pixel dimension in its LDS reads (no channel-major
+ *   copies; the workspace then holds the fp32 partial tiles only).  lss_conv2d_wgrad_timeouts: flag waits of that
+ *   kernel that hit their bound since load (must be 0; synchronises the device).
  */
 int lss_conv2d_pack_weights_dgrad(const float* w_oihw, int Cout, int Cin, int KH, int KW, int dt,
                                   void* w_packed, void* stream);
 size_t lss_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int lss_conv2d_wgrad(const void* x, const void* dy, int B, int H, int W, int Cin, int Cout,
                      void* workspace, size_t workspace_bytes, float* dw_oihw, void* stream);
+int lss_conv2d_wgrad_timeouts(void);
 
 /* Backward helpers of the fused upsample + concat conv input (ref Up.forward, src/modules.py:22-24;
  * bf16 NHWC).  lss_upsample_cat_nhwc materialises [x2 | bilinear_align_corners(x, up)] as

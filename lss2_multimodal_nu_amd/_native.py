@@ -48,6 +48,7 @@ SIGNATURES = {
     "lss_conv2d_ring_packed_weight_bytes": (_sz, [_i, _i]),
     "lss_conv2d_pack_weights_ring": (_i, [_vp, _i, _i, _vp, _vp]),
     "lss_conv2d_pack_weights_ring_dgrad": (_i, [_vp, _i, _i, _vp, _vp]),
+    "lss_conv2d_wgrad_timeouts": (_i, []),
     "lss_conv2d_ring_timeouts": (_i, []),
     "lss_conv2d_pack_weights_dgrad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lss_conv2d_wgrad_workspace_bytes": (_sz, [_i] * 5),

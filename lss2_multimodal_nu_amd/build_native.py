@@ -29,6 +29,7 @@ SOURCES = {
     "linear_mfma.hip": [],
     "ffn_fused.hip": [],
     "conv_grad.hip": [],
+    "conv_wgrad.hip": [],
     "bn_train.hip": [],
     "loss.hip": [],
     "rccl_bucket.hip": [],  # host code only: RCCL resolved with dlsym at run time (no -lrccl)

@@ -21,6 +21,10 @@
 int lss_wgrad_gemm_launch(const void* dyt, const void* const xt[3], float* partial, int M, int N,
                           long long ld, long long split_k, int nsplit, int ntap, long long tap_row,
                           hipStream_t st);  // linear_mfma.hip
+// conv_wgrad.hip: the direct kernel (NHWC operands as they lie, transposed reads); 0 splits = not a case for it
+int lss_wgrad_direct_splits(int B, int H, int W, int Cin, int Cout);
+int lss_wgrad_direct_launch(const void* x, const void* dy, int B, int H, int W, int Cin, int Cout, float* partial,
+                            hipStream_t st);
 
 namespace {
 
@@ -279,6 +283,8 @@ extern "C" int lss_conv2d_pack_weights_dgrad(const float* w_oihw, int Cout, int 
 
 extern "C" size_t lss_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const int nd = lss_wgrad_direct_splits(B, H, W, Cin, Cout);
+  if (nd > 0) return align256((size_t)nd * 9 * Cout * Cin * 4);  // the direct kernel: fp32 partial tiles only
   const WgradGeom g = wgrad_geom(B, H, W, Cin, Cout);
   return align256((size_t)3 * Cin * g.ld * 2) + align256((size_t)Cout * g.ld * 2) +
          align256((size_t)g.nsplit * 9 * Cout * Cin * 4);
@@ -291,8 +297,18 @@ extern "C" int lss_conv2d_wgrad(const void* x, const void* dy, int B, int H, int
   if (Cin % 8 != 0 || Cout % 8 != 0 || W > 4096) return LSS_E_SHAPE;
   if (workspace_bytes < lss_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout)) return LSS_E_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return LSS_E_ALIGN;
-  const WgradGeom g = wgrad_geom(B, H, W, Cin, Cout);
   hipStream_t st = lss_stream(stream);
+  const int nd = lss_wgrad_direct_splits(B, H, W, Cin, Cout);
+  if (nd > 0) {  // K9w (conv_wgrad.hip), then the same fixed-order reduction over its splits
+    float* partial = static_cast<float*>(workspace);
+    int rc = lss_wgrad_direct_launch(x, dy, B, H, W, Cin, Cout, partial, st);
+    if (rc != 0) return rc;
+    const size_t n = (size_t)9 * Cout * Cin;
+    const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, partial, nd, Cout, Cin, dw_oihw);
+    return lss_launch_status();
+  }
+  const WgradGeom g = wgrad_geom(B, H, W, Cin, Cout);
   unsigned char* ws = static_cast<unsigned char*>(workspace);
   unsigned short* xt = reinterpret_cast<unsigned short*>(ws);
   const size_t xt_bytes = align256((size_t)3 * Cin * g.ld * 2);

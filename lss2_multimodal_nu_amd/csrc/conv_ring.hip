@@ -44,7 +44,6 @@ constexpr int RK_STRIP_PATCH = RK_PH * RK_PW * RK_POSB;   // 9216 B = 9 DMA piec
 constexpr int RK_SLAB = 128 * RK_KC * 2;      // 8192 B = 8 DMA pieces
 constexpr int RK_SRC_H = 5, RK_SRC_W = 14;    // low-res source window of a strip patch (scale factors >= 2)
 constexpr int RK_SRC_STRIP = RK_SRC_H * RK_SRC_W * RK_POSB;  // 4480 B
-constexpr int RK_SPIN_LIMIT = 1 << 16;        // bound of every flag wait (~10 ms): a protocol bug must end the grid, not hang it
 
 struct RingArgs {
   const unsigned short* x;    // (B, H, W, Cx) bf16 NHWC; the low-res source when up > 1
@@ -80,48 +79,8 @@ struct RingLds {
 // flag words (ints at FLAGS)
 constexpr int F_FULL_W = 0, F_FREE_W = 8, F_FULL_P = 16, F_FREE_P = 18, F_HEAD = 20, F_FULL_S = 24, F_FREE_S = 25;
 
-__device__ __forceinline__ void rk_glds16(const void* gsrc, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-template <int N>
-__device__ __forceinline__ void rk_wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void rk_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-// Flag words live in LDS and are addressed through address_space(3) pointers: a generic `volatile int*` made
-// hipcc emit flat_load ... sc0 sc1 followed by vmcnt(0) waits (seen in the ISA of the first build).
-typedef __attribute__((address_space(3))) volatile int* rk_flag_t;
-// wave-uniform read of a flag word
-__device__ __forceinline__ int rk_peek(rk_flag_t f) { return __builtin_amdgcn_readfirstlane(*f); }
-// wait until *f >= need (bounded)
-template <int SLEEP = 1>
-__device__ __forceinline__ int rk_wait_ge(rk_flag_t f, int need) {
-  int v = rk_peek(f);
-  int n = 0;
-  while (v < need) {
-    __builtin_amdgcn_s_sleep(SLEEP);  // units of 64 cycles
-    v = rk_peek(f);
-    if (++n > RK_SPIN_LIMIT) {
-      if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&lss_ring_timeouts, 1);
-      break;
-    }
-  }
-  asm volatile("" ::: "memory");  // nothing that reads the handed-over buffer may move above the wait
-  return n;
-}
-__device__ __forceinline__ void rk_set(rk_flag_t f, int v, int lane) {
-  if (lane == 0) *f = v;
-}
-// FREE counters: one no-return LDS atomic from lane 0 (inline asm: the compiler's atomic optimiser otherwise wraps
-// every add in a wave reduction; an LDS operation it does not know of only makes its counted lgkmcnt waits stricter)
-__device__ __forceinline__ void rk_add1(rk_flag_t f, int lane) {
-  if (lane == 0) {
-    const unsigned int addr = (unsigned int)(__UINTPTR_TYPE__)f;
-    asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1) : "memory");
-  }
-}
+#define RK_TIMEOUT_COUNTER lss_ring_timeouts
+#include "ring_prims.h"
 
 // bilinear blend of four 8-channel bf16 pieces in the four-weight form: r = q00 w00, then fma(q01, w01, r), fma(q10,
 // w10, r), fma(q11, w11, r) per channel - the operation order of conv_mfma.hip's blend_bf16x8, so the fused-gather

@@ -14,6 +14,11 @@ SHAPES = [  # B, H, W, Cin, Cout
     (2, 50, 50, 128, 128),   # layer2-like
     (1, 9, 7, 64, 192),      # Cin != Cout, tiny image (more guard than image)
     (4, 100, 100, 64, 64),   # layer1 at the bench batch
+    (2, 100, 100, 320, 256), # up1.conv[0]: five input-channel tiles
+    (1, 200, 200, 256, 128), # up2: seven K blocks per row, four row slots
+    (1, 61, 83, 64, 128),    # ragged width (three K blocks, the last one 19 positions)
+    (1, 6, 224, 64, 64),     # the widest row the direct kernel takes
+    (3, 5, 113, 128, 64),    # more splits than image rows allow: short row ranges, pad rows inside a range
 ]
 
 
@@ -38,6 +43,21 @@ def test_conv3x3_wgrad_vs_torch(shape):
     # fixed summation order: bitwise reproducible, also with a dirty workspace from another call
     ops.conv3x3_wgrad(dy.cuda()[..., :Cin].contiguous() if Cout >= Cin else x.cuda(), dy.cuda())
     assert torch.equal(dw, ops.conv3x3_wgrad(x.cuda(), dy.cuda()))
+    assert ops.N.lib().lss_conv2d_wgrad_timeouts() == 0, "a flag wait of the direct wgrad kernel hit its bound"
+
+
+def test_conv3x3_wgrad_gemm_path_still_agrees(monkeypatch):
+    """LSS_WGRAD_DIRECT=0: the channel-major copies + split-K GEMM (the only path for widths outside 8..224 or
+    channel counts that are not multiples of 64) against the direct kernel on a shape both take."""
+    shape = (2, 50, 50, 128, 128)
+    x, dy, _ = _operands(*shape, seed=5)
+    direct = ops.conv3x3_wgrad(x.cuda(), dy.cuda())
+    monkeypatch.setenv("LSS_WGRAD_DIRECT", "0")
+    ops._wgrad_ws.clear()
+    gemm = ops.conv3x3_wgrad(x.cuda(), dy.cuda())
+    monkeypatch.delenv("LSS_WGRAD_DIRECT")
+    ops._wgrad_ws.clear()
+    assert float((direct - gemm).abs().max()) <= 1e-4 * float(gemm.abs().max())
 
 
 @pytest.mark.parametrize("shape", SHAPES[:4])
