@@ -445,7 +445,9 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     torch.manual_seed(0)
     m = L.compile_model_lss(B, GRID, AUG, 4, precision=args.precision).to(dev).train()
     bucket = dp.make_bucket(m)  # every p.grad is a view of one flat buffer; all-reduce starts inside backward
-    opt = torch.optim.Adam(bucket.params, lr=1e-4, weight_decay=1e-8)  # ref: train.py:42
+    # one HIP graph per step when this is the only rank (dp.GraphedTrainStep; LSS_TRAIN_GRAPH=0: eager launches)
+    want_graph = world == 1 and os.environ.get("LSS_TRAIN_GRAPH", "1") != "0"
+    opt = torch.optim.Adam(bucket.params, lr=1e-4, weight_decay=1e-8, capturable=want_graph)  # ref: train.py:42
     tgt = torch.randint(0, 4, (B, 200, 200), device=dev)
     weight = torch.tensor([1.0, 10.0, 5.0, 10.0], device=dev)         # ref: src/tools.py:234
 
@@ -471,6 +473,17 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     def one():  # ref: train.py:49-66 (zero_grad, forward, loss, backward, clip 5.0, Adam) + the DP all-reduce
         dp.train_step(wrapped, bucket, opt, loss_fn, (feats,) + tuple(calib), clip=5.0)
 
+    graph_note = "eager launches (%s)" % ("world_size > 1" if world > 1 else "LSS_TRAIN_GRAPH=0")
+    if want_graph:
+        try:
+            graphed = dp.GraphedTrainStep(wrapped, bucket, opt, loss_fn, feats, tuple(calib), clip=5.0, warmup=5)
+
+            def one():  # noqa: F811  (the same step, replayed: features and calibration refreshed every step)
+                graphed(feats, tuple(calib))
+            graph_note = "one HIP graph per step (dp.GraphedTrainStep): features + calibration refreshed, then one replay"
+        except Exception as e:  # capture refused by a library call: the eager step is still valid
+            graph_note = "eager launches (graph capture failed: %s)" % (str(e).splitlines()[0][:160],)
+            torch.cuda.synchronize()
     for _ in range(5):  # MIOpen's first-call kernel selection, Adam state, allocator growth: all outside the timed steps
         one()
     if dist is not None:
@@ -491,7 +504,7 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
             "grad_buckets": [(hi - lo) * 4 / 1e6 for lo, hi, _ in bucket.buckets],
             "allreduce": ("direct RCCL (lss_allreduce_bucket)" if bucket._direct is not None else
                           ("torch.distributed %s" % dist.get_backend() if dist is not None else "none (1 rank)")),
-            "amp_bf16": amp,
+            "amp_bf16": amp, "launch": graph_note,
             "note": "lift-splat fwd/bwd native HIP (fp32); under bf16 autocast every 3x3/s1 conv + BatchNorm(train) + "
                     "residual + ReLU unit of BevEncode (95 % of its FLOPs) is one HIP autograd node: conv fwd / dgrad / "
                     "wgrad, BN fwd / bwd, fused upsample+concat and its adjoint (LSS_TRAIN_NATIVE=0 = library path for "

@@ -251,3 +251,59 @@ def train_step(model, bucket, opt, loss_fn, inputs, clip=5.0):
     if unused:
         bucket.attach()
     return loss.detach()
+
+
+class GraphedTrainStep:
+    """`train_step` captured once in a HIP graph and replayed: the ~300 launches of a step (19 conv + BatchNorm
+    units forward and backward, the lift-splat pair, loss, clip, Adam) leave the host as ONE launch, so the step
+    runs at the speed of its kernels instead of the speed of the Python / autograd dispatch around them (measured:
+    the eager step is host-bound once the weight-gradient kernels are fast).
+
+    Everything a step reads from outside lives in STATIC device buffers that `__call__` refreshes before the
+    replay: the feature tensor, the targets the loss function closes over (pass them as `extra_static` pairs
+    `(static_device_tensor, new_value)` through `__call__(..., refresh=...)`), and the calibration as a
+    device-resident `CalibrationPack` (host inverses as always, data.prepare_calibration; one H2D copy per step).
+    The optimizer must be built with `capturable=True`.  Single process only: with world_size > 1 the bucket
+    all-reduce is a cross-stream RCCL launch and the step stays eager (`train_step`)."""
+
+    def __init__(self, model, bucket, opt, loss_fn, feats, calib, clip=5.0, warmup=3):
+        from .data import CalibrationPack, prepare_calibration
+        if not feats.is_cuda:
+            raise ValueError("GraphedTrainStep: features must be on the GPU")
+        if bucket._world() > 1:
+            raise RuntimeError("GraphedTrainStep is single-process; use train_step under data parallelism")
+        self._prepare = prepare_calibration
+        self.feats = feats.detach().clone()
+        host = calib if isinstance(calib, CalibrationPack) else prepare_calibration(*calib)
+        self.pack = CalibrationPack(host.buffer.to(feats.device), host.shape)
+        self._inputs = (self.feats, self.pack, None, None, None, None)
+
+        def step():
+            return train_step(model, bucket, opt, loss_fn, self._inputs, clip=clip)
+
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):  # first-call work (kernel selection, optimizer state, allocator growth)
+            for _ in range(warmup):
+                step()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = step()
+
+    def __call__(self, feats, calib, refresh=()):
+        """One step on new inputs; returns the (static) loss tensor.  `refresh`: (static_tensor, new_value) pairs
+        of anything else the captured step reads (e.g. the target tensor of the loss function)."""
+        from .data import CalibrationPack
+        if feats is not self.feats:
+            self.feats.copy_(feats, non_blocking=True)
+        if calib is not None:
+            host = calib if isinstance(calib, CalibrationPack) else self._prepare(*calib)
+            if host.buffer is not self.pack.buffer:
+                self.pack.buffer.copy_(host.buffer, non_blocking=True)
+        for dst, src in refresh:
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.loss

@@ -162,3 +162,57 @@ def test_direct_rccl_binding_single_rank():
             N.check(N.lib().lss_allreduce_bucket(comm, N.ptr(y), 0, N.stream()), "lss_allreduce_bucket")
     finally:
         N.check(N.lib().lss_rccl_comm_destroy(comm), "lss_rccl_comm_destroy")
+
+
+def test_graphed_train_step_equals_eager():
+    """dp.GraphedTrainStep (one HIP graph per step, static feature / calibration buffers refreshed before each
+    replay) against dp.train_step on the same three batches: same losses, same parameters afterwards - and the
+    replays must FOLLOW the new inputs (a graph that froze the first batch would repeat its loss)."""
+    import lss2_multimodal_nu_amd as L
+    from lss2_multimodal_nu_amd import dp
+    from oracle import lss_oracle as lo
+    dev = torch.device("cuda:0")
+    tgt = torch.randint(0, 4, (1, 200, 200), generator=torch.Generator().manual_seed(9)).to(dev)
+    batches = []
+    for s in range(3):
+        g = torch.Generator().manual_seed(40 + s)
+        batches.append((torch.randn(6, 512, 8, 22, generator=g).to(dev), lo.synthetic_rig(1, 6, train_aug=True, seed=s)))
+
+    def build():
+        torch.manual_seed(0)
+        m = L.compile_model_lss(1, GRID, AUG, 4, precision="bf16").to(dev).train()
+        bucket = dp.make_bucket(m)
+        opt = torch.optim.Adam(bucket.params, lr=1e-3, capturable=True)
+
+        class Amp(torch.nn.Module):
+            def __init__(self, inner):
+                super().__init__()
+                self.inner = inner
+
+            def forward(self, *a):
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    return self.inner.forward_loss(*a, tgt)
+
+        return m, bucket, opt, Amp(m)
+
+    # eager: warm-up steps on batch 0 (the graphed build does the same number inside its constructor + capture)
+    m1, b1, o1, w1 = build()
+    WARM = 3
+    for _ in range(WARM):
+        dp.train_step(w1, b1, o1, lambda l: l, (batches[0][0],) + tuple(batches[0][1]))
+    eager = [float(dp.train_step(w1, b1, o1, lambda l: l, (f,) + tuple(c))) for f, c in batches]
+
+    m2, b2, o2, w2 = build()
+    gs = dp.GraphedTrainStep(w2, b2, o2, lambda l: l, batches[0][0], tuple(batches[0][1]), warmup=WARM)
+    graphed = [float(gs(f, tuple(c))) for f, c in batches]
+    assert len(set(round(v, 6) for v in graphed)) == 3, graphed  # three batches, three losses
+    for a, b in zip(eager, graphed):
+        assert abs(a - b) <= 2e-3 * abs(a), (eager, graphed)
+    worst = 0.0
+    for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        d = float((p1.detach() - p2.detach()).abs().max())
+        worst = max(worst, d / (float(p1.abs().max()) + 1e-6))
+        # Adam's first steps move every weight by ~lr whatever the gradient's size: a sign flip of a tiny gradient
+        # (bf16 noise between two runs of the library convs) is worth 2 lr
+        assert d <= 6 * 1e-3 * (WARM + 3) * 0.5 + 1e-6, (n1, d)
+    print("graphed vs eager: losses", eager, graphed, "worst relative parameter difference", worst)
