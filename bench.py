@@ -444,10 +444,18 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     from lss2_multimodal_nu_amd import dp
     torch.manual_seed(0)
     m = L.compile_model_lss(B, GRID, AUG, 4, precision=args.precision).to(dev).train()
-    bucket = dp.make_bucket(m)  # every p.grad is a view of one flat buffer; all-reduce starts inside backward
+    # N > 1: every p.grad is a view of one flat buffer and the bucket all-reduces start inside backward.
+    # N = 1: the reference's loop as it stands (dp.train_step_local) - no flat buffer, no per-parameter `grad += g`
+    bucket = dp.make_bucket(m) if world > 1 else None
+    params = bucket.params if bucket is not None else [p for p in m.parameters() if p.requires_grad]
     # one HIP graph per step when this is the only rank (dp.GraphedTrainStep; LSS_TRAIN_GRAPH=0: eager launches)
     want_graph = world == 1 and os.environ.get("LSS_TRAIN_GRAPH", "1") != "0"
-    opt = torch.optim.Adam(bucket.params, lr=1e-4, weight_decay=1e-8, capturable=want_graph)  # ref: train.py:42
+    try:  # the fused single-kernel Adam (same update rule as train.py:42's torch.optim.Adam) where the build has it
+        opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-8, capturable=want_graph, fused=True)
+        adam = "fused"
+    except Exception:
+        opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-8, capturable=want_graph)
+        adam = "foreach"
     tgt = torch.randint(0, 4, (B, 200, 200), device=dev)
     weight = torch.tensor([1.0, 10.0, 5.0, 10.0], device=dev)         # ref: src/tools.py:234
 
@@ -500,10 +508,11 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt[0])
     return {"samples_per_s": args.train_steps * B * world / dt, "ms_per_step": dt / args.train_steps * 1e3,
-            "steps": args.train_steps, "grad_bucket_MB": bucket.numel * 4 / 1e6,
-            "grad_buckets": [(hi - lo) * 4 / 1e6 for lo, hi, _ in bucket.buckets],
-            "allreduce": ("direct RCCL (lss_allreduce_bucket)" if bucket._direct is not None else
-                          ("torch.distributed %s" % dist.get_backend() if dist is not None else "none (1 rank)")),
+            "steps": args.train_steps, "grad_bucket_MB": sum(p.numel() for p in params) * 4 / 1e6,
+            "grad_buckets": [(hi - lo) * 4 / 1e6 for lo, hi, _ in bucket.buckets] if bucket is not None else [],
+            "allreduce": ("none (1 rank)" if bucket is None else "direct RCCL (lss_allreduce_bucket)"
+                          if bucket._direct is not None else "torch.distributed %s" % dist.get_backend()),
+            "adam": adam,
             "amp_bf16": amp, "launch": graph_note,
             "note": "lift-splat fwd/bwd native HIP (fp32); under bf16 autocast every 3x3/s1 conv + BatchNorm(train) + "
                     "residual + ReLU unit of BevEncode (95 % of its FLOPs) is one HIP autograd node: conv fwd / dgrad / "

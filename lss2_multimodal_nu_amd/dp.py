@@ -240,7 +240,10 @@ def make_bucket(model_or_params, group=None, n_buckets=3, overlap=True):
 
 
 def train_step(model, bucket, opt, loss_fn, inputs, clip=5.0):
-    """One data-parallel step: fwd, bwd (bucket all-reduces start inside it), mean, clip, optimizer."""
+    """One data-parallel step: fwd, bwd (bucket all-reduces start inside it), mean, clip, optimizer.
+    `bucket=None`: the single-process form (`train_step_local`)."""
+    if bucket is None:
+        return train_step_local(model, opt, loss_fn, inputs, clip)
     bucket.zero()
     loss = loss_fn(model(*inputs))
     loss.backward()
@@ -250,6 +253,22 @@ def train_step(model, bucket, opt, loss_fn, inputs, clip=5.0):
     opt.step()
     if unused:
         bucket.attach()
+    return loss.detach()
+
+
+def train_step_local(model, opt, loss_fn, inputs, clip=5.0):
+    """The reference's loop body as it stands (train.py:49-66: zero_grad, forward, loss, backward,
+    clip_grad_norm_(5.0), step) for ONE process: no flat buffer.  With `.grad = None` at the start autograd hands
+    each parameter its gradient tensor as produced (no `grad += g` kernel per parameter: 62 launches a step on
+    the bucket path, whose flat buffer only the all-reduce needs); clipping is torch's foreach form (no host
+    sync)."""
+    params = [p for g in opt.param_groups for p in g["params"]]
+    for p in params:
+        p.grad = None
+    loss = loss_fn(model(*inputs))
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], clip, foreach=True)
+    opt.step()
     return loss.detach()
 
 
@@ -270,7 +289,7 @@ class GraphedTrainStep:
         from .data import CalibrationPack, prepare_calibration
         if not feats.is_cuda:
             raise ValueError("GraphedTrainStep: features must be on the GPU")
-        if bucket._world() > 1:
+        if bucket is not None and bucket._world() > 1:
             raise RuntimeError("GraphedTrainStep is single-process; use train_step under data parallelism")
         self._prepare = prepare_calibration
         self.feats = feats.detach().clone()
