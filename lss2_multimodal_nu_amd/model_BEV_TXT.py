@@ -64,15 +64,16 @@ class TrunkFeatures(nn.Module):
 
 
 class _LiftSplatFn(torch.autograd.Function):
-    """depthnet -> softmax -> lift -> splat as ONE differentiable op (K2,K5 | K7).
-    Index tensors come from the workspace (K3/K4 already ran)."""
+    """geometry -> depthnet -> softmax -> lift -> splat as ONE differentiable op.  The forward is the inference
+    pipeline (`lss_lift_splat_forward`: K2 || K3, region fill, region splat - LDS-privatised histograms, no per-point
+    global atomics); it leaves the voxel ids, depth and context tensors K7 needs for the backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, ws, dims, nx, math, layout):
-        B, N, D, fH, fW, C = dims
-        depth, feat = ops.depthnet_softmax(x.contiguous(), weight, bias, D, C, math)
-        ops.bucket_points(ws, depth)
-        bev = ops.lift_splat_fwd(feat, ws, dims, nx, layout)
+    def forward(ctx, x, weight, bias, calib, consts, ws, dims, nx, math, layout):
+        inv_pr, comb, ptr, trn = calib
+        frustum, dx, bx = consts
+        bev, depth, feat = ops.lift_splat_forward(frustum, inv_pr, ptr, comb, trn, dx, bx, x.contiguous(), weight, bias,
+                                                  ws, dims, nx, layout, math)
         ctx.save_for_backward(x, weight, depth, feat, ws.voxel.clone())
         ctx.dims, ctx.nx = dims, nx
         return bev
@@ -89,7 +90,7 @@ class _LiftSplatFn(torch.autograd.Function):
         gx = torch.matmul(w2.t().unsqueeze(0), gl).view_as(x) if ctx.needs_input_grad[0] else None
         gw = torch.einsum("bnp,bkp->nk", gl, xf).view_as(weight) if ctx.needs_input_grad[1] else None
         gb = gl.sum((0, 2)) if ctx.needs_input_grad[2] else None
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None
 
 
 class _VoxelPoolFn(torch.autograd.Function):
@@ -309,10 +310,13 @@ class _LiftSplatMixin:
         dims = (B, BN // B, self.D, fH, fW, self.camC)
         ce = self.camencode
         if _needs_autograd(ce, x):
-            ws, _ = self._index_points(rots, trans, intrins, post_rots, post_trans)
-            with _histogram_guard(ws):  # K3 ran; K4 runs inside the autograd node, after the operand checks
-                return _LiftSplatFn.apply(x.float(), ce.depthnet.weight, ce.depthnet.bias, ws, dims,
-                                          self._nx_ints(), _PRECISIONS[ce.math], layout)
+            dev = self.frustum.device
+            nx = self._nx_ints()
+            ws = self._workspace(B * dims[1] * self.D * fH * fW, B * nx[0] * nx[1] * nx[2], dev)
+            calib = self._device_calib(dev, rots, trans, intrins, post_rots, post_trans)
+            return _LiftSplatFn.apply(x.float(), ce.depthnet.weight, ce.depthnet.bias, calib,
+                                      (self.frustum.detach(), self.dx.detach(), self.bx.detach()), ws, dims, nx,
+                                      _PRECISIONS[ce.math], layout)
         # inference: K3 -> K2 -> K4 -> K5 through one native call
         dev = self.frustum.device
         nx = self._nx_ints()

@@ -95,6 +95,38 @@ class _Conv3x3Fn(torch.autograd.Function):
         return gx, gw
 
 
+class _ConvS2Fn(torch.autograd.Function):
+    """Bias-free stride-2 conv (the 7x7 / 2 stem, the 3x3 / 2 first convs and the 1x1 / 2 shortcuts of layer2 / layer3;
+    ref src/modules.py:99 + torchvision BasicBlock) with the FORWARD on the same K8 phase-plane kernel as inference
+    (bf16 NHWC, fp32 accumulation); the two gradients are the library's convolution_backward on the saved bf16
+    operands (5 small layers: 8 % of a training step - DESIGN.md section 9)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, pad):
+        xn = x.permute(0, 2, 3, 1)
+        if xn.dtype != torch.bfloat16:
+            xn = xn.to(torch.bfloat16)
+        xn = xn.contiguous()  # no copy when x is already channels_last bf16
+        w32 = weight.detach().float().contiguous()
+        K = weight.shape[2]
+        wp = ops.pack_conv_weight_s2d(w32, pad) if K > 1 else ops.pack_conv_weight(w32, ops.DT_BF16)
+        y = ops.conv2d_s2_nhwc(xn, wp, K, pad, tag="conv2d_train_fwd")
+        ctx.save_for_backward(xn, weight)
+        ctx.cfg = (x.dtype, pad)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xn, weight = ctx.saved_tensors
+        x_dtype, pad = ctx.cfg
+        g = gy if gy.dtype == torch.bfloat16 else gy.to(torch.bfloat16)
+        gx, gw, _ = torch.ops.aten.convolution_backward(
+            g.contiguous(memory_format=torch.channels_last), xn.permute(0, 3, 1, 2), weight.detach().to(torch.bfloat16),
+            None, [2, 2], [pad, pad], [1, 1], False, [0, 0], 1,
+            [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
+        return (None if gx is None else gx.to(x_dtype), None if gw is None else gw.to(weight.dtype), None)
+
+
 class _UpConv3x3Fn(torch.autograd.Function):
     """conv3x3(cat([x2, bilinear_align_corners(x1, up)])) with the upsample and the concat fused into
     the conv's operand gather in the forward (neither tensor exists), and in the backward: one dgrad
@@ -355,6 +387,11 @@ def _train_conv(conv, x):
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
             and conv.in_channels % 64 == 0 and conv.out_channels % 8 == 0 and _native_training()):
         return _Conv3x3Fn.apply(x, conv.weight)
+    k, p = conv.kernel_size[0], conv.padding[0]
+    if (x.is_cuda and conv.stride == (2, 2) and conv.kernel_size in ((1, 1), (3, 3), (7, 7)) and conv.padding == (k // 2, k // 2)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.in_channels % 64 == 0
+            and conv.out_channels % 64 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and _native_training()):
+        return _ConvS2Fn.apply(x, conv.weight, p)
     return conv(x)
 
 
@@ -616,7 +653,7 @@ class BasicBlock(nn.Module):
         self._fd = _FoldedConv(self.downsample[0], self.downsample[1]) if self.downsample is not None else None
 
     def forward(self, x):
-        idt = x if self.downsample is None else _train_bn_act(self.downsample[1], self.downsample[0](x), relu=False)
+        idt = x if self.downsample is None else _train_bn_act(self.downsample[1], _train_conv(self.downsample[0], x), relu=False)
         out = _train_conv_bn_act(self.conv1, self.bn1, x, relu=True)
         return _train_conv_bn_act(self.conv2, self.bn2, out, relu=True, residual=idt)
 
@@ -699,7 +736,7 @@ class BevEncode(nn.Module):
             x = x.contiguous(memory_format=torch.channels_last)  # the whole chain then stays NHWC
         outer, _batch_counters[0] = _batch_counters[0], []
         try:
-            x = _train_bn_act(self.bn1, self.conv1(x), relu=True)
+            x = _train_bn_act(self.bn1, _train_conv(self.conv1, x), relu=True)
             x1 = self.layer1(x)
             x = self.layer3(self.layer2(x1))
             x = self.up1(x, x1)
