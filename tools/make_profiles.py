@@ -76,7 +76,10 @@ def main():
                      ("bk_l1.txt", "l1_microbench.txt"), ("l1_stamps.txt", "l1_stamps.txt"),
                      ("ring_microbench.txt", "ring_microbench.txt"), ("ring_wait_stats.txt", "ring_wait_stats.txt"),
                      ("ring_microbench_noblend.txt", "ring_microbench_noblend.txt"),
-                     ("ring_microbench_nowdma.txt", "ring_microbench_nowdma.txt")):
+                     ("ring_microbench_nowdma.txt", "ring_microbench_nowdma.txt"),
+                     ("ring_microbench_readsonly.txt", "ring_microbench_readsonly.txt"),
+                     ("ring_microbench_oneread.txt", "ring_microbench_oneread.txt"),
+                     ("wgrad_microbench.txt", "wgrad_microbench.txt")):
         p = os.path.join(src, tag)
         if os.path.exists(p):
             w(out, "".join(ln for ln in open(p) if "amdgpu.ids" not in ln))

@@ -24,6 +24,9 @@ python tools/bench_ring.py > $OUT/ring_microbench.txt 2>&1
 [ -f diag_libs/liblss_STATS.so ] && LSS_HIP_LIB=$R/diag_libs/liblss_STATS.so python tools/ring_stats.py > $OUT/ring_wait_stats.txt 2>&1
 [ -f diag_libs/liblss_NOBLEND.so ] && LSS_HIP_LIB=$R/diag_libs/liblss_NOBLEND.so python tools/bench_ring.py > $OUT/ring_microbench_noblend.txt 2>&1
 [ -f diag_libs/liblss_NOWDMA.so ] && LSS_HIP_LIB=$R/diag_libs/liblss_NOWDMA.so python tools/bench_ring.py > $OUT/ring_microbench_nowdma.txt 2>&1
+[ -f diag_libs/liblss_READSONLY.so ] && LSS_HIP_LIB=$R/diag_libs/liblss_READSONLY.so python tools/bench_ring.py > $OUT/ring_microbench_readsonly.txt 2>&1
+[ -f diag_libs/liblss_ONEREAD.so ] && LSS_HIP_LIB=$R/diag_libs/liblss_ONEREAD.so python tools/bench_ring.py > $OUT/ring_microbench_oneread.txt 2>&1
+python tools/bench_wgrad.py > $OUT/wgrad_microbench.txt 2>&1
 echo "microbenches done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $R/bench.py $ARGS > $OUT/kt.log 2>&1
