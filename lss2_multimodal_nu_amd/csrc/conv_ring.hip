@@ -10,24 +10,30 @@
 // Geometry.  Output pixels are cut into STRIPS of 4 rows x 20 columns = five 4x4-pixel blocks; a block is the 16
 // columns of one v_mfma_f32_16x16x32_bf16 (A = 16 output channels x 32 input channels of the weights, B = 32 input
 // channels x 16 pixels of the patch).  100 and 200 are multiples of 20 and of 4, so the 100^2 / 200^2 layers tile
-// with NO waste (round 2's 8 x 16 tiles covered 104 x 112: +16.5 % MFMAs at 100^2), and a workgroup = 2 strips x 128
-// output channels gives 500 workgroups at 100^2 x 256 channels x batch 4 and 1000 at 200^2 x 128 channels: one / two
-// full rounds of the 512 resident slots (2 workgroups per CU), 97.6 % full.
-//   consumer wave w (0..3): strip w >> 1, channel half w & 1 -> 5 blocks x 4 channel tiles = 20 accumulators of 4
-//   registers.  The rows of channel tile t are the channels {16 q + 4 t + i}: lane (q = lane >> 4, n = lane & 15)
-//   then ends with 16 CONSECUTIVE channels of pixel n in its 16 accumulator registers of a block, and the epilogue
-//   stores 2 x 16 B per block straight from registers (no LDS staging pass; round 2: 19 % of up1.conv3).
-// K loop: chunk = 32 input channels, step = (chunk, tap): 20 MFMAs per wave against one 8-KiB weight slab.
-// LDS (78-80 KiB, two workgroups per CU):
-//   ring   NSL slots x 8 KiB  weight slab of one step in FRAGMENT ORDER (piece (cg, t, lane) at ((cg*4+t)*64+lane)*16:
-//          a consumer reads its A fragment lane-linearly = conflict-free); the packed weights in global memory have
-//          exactly this image, so a slab is 8 fully coalesced 1-KiB DMA pieces
-//   patch  2 buffers x 2 strips x (6 rows x 24 positions x 64 B): position-major, the four 16-B channel pieces of a
+// with NO waste (round 2's 8 x 16 tiles covered 104 x 112: +16.5 % MFMAs at 100^2).  A workgroup = 4 strips x 128
+// output channels, ONE per CU (250 workgroups at 100^2 x 256 channels x batch 4: 97.6 % of one round; 500 at
+// 200^2 x 128 channels: two rounds), 12 waves = three per SIMD:
+//   waves 0-7  consumers: strip w >> 1, channel half w & 1 -> 5 blocks x 4 channel tiles = 20 accumulators of 4
+//              registers.  The rows of channel tile t are the channels {16 q + 4 t + i}: lane (q = lane >> 4,
+//              n = lane & 15) then ends with 16 CONSECUTIVE channels of pixel n in its 16 accumulator registers of a
+//              block, and the epilogue stores straight from registers (no LDS staging pass; round 2: 19 % of
+//              up1.conv3) - after two row swaps (v_permlane16_swap / v_permlane32_swap) that give the four q lanes of
+//              a pixel consecutive 16-B pieces, so one store instruction covers 64 contiguous bytes per pixel
+//   wave  8    weight loader: streams the weight slabs by LDS-DMA
+//   waves 9-11 patch loaders: plain DMA of the input patch, or source-window DMA + four-corner blend (fused upsample)
+// K loop: chunk = 32 input channels, step = (chunk, tap): 20 MFMAs per consumer against one 8-KiB weight slab.
+// LDS (140-154 KiB):
+//   ring   NSL (7-8) slots x 8 KiB: the weight slab of one step in FRAGMENT ORDER (piece (cg, t, lane) at
+//          ((cg*4+t)*64+lane)*16: a consumer reads its A fragment lane-linearly = conflict-free); the packed weights
+//          in global memory have exactly this image, so a slab is 8 fully coalesced 1-KiB DMA pieces
+//   patch  2 buffers x 4 strips x (6 rows x 24 positions x 64 B): position-major, the four 16-B channel pieces of a
 //          position XOR-swizzled by (row & 1) << 1 - conflict-free ds_read_b128 for every tap shift (checked by
-//          enumeration over the hardware's b128 lane groups, tools/lds_bank_check.py)
-//   src    (fused upsample) the low-res source window of a chunk, 2 strips x 5 x 14 positions
+//          enumeration over the hardware's b128 lane groups)
+//   src    (fused upsample) the low-res source window of a chunk, 4 strips x 5 x 14 positions
+//   headx  (fused head) the partial class sums of the second channel half
 //   flags  FULL_W[slot] = fill count (weight loader), FREE_W[slot] = releases (consumers, LDS atomic add),
-//          FULL_P / FREE_P the same for the two patch buffers
+//          FULL_P / FREE_P the same for the two patch buffers, FULL_S / FREE_S for the source window
+// Every flag wait is bounded (ring_prims.h); lss_conv2d_ring_timeouts() must read 0.
 #include <stdlib.h>
 
 #include <type_traits>
