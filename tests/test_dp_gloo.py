@@ -241,3 +241,27 @@ def test_direct_collective_runs_on_a_fenced_side_stream(monkeypatch):
     waits = fake.log[8:]
     assert [w[:2] for w in waits] == [("wait", "compute")] * 2
     assert {w[2] for w in waits} == {fake.log[3][1], fake.log[7][1]}
+
+
+def test_train_step_local_equals_bucket_step_single_process():
+    """dp.train_step_local (the reference's loop as it stands: grads set to None, clip_grad_norm_, step) and the bucket
+    form of dp.train_step produce the same parameters on one process - the bucket's flat buffer changes where the
+    gradients live, not what they are."""
+    import copy
+
+    import torch
+
+    from lss2_multimodal_nu_amd import dp
+    torch.manual_seed(0)
+    base = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 8), torch.nn.Linear(8, 2))
+    xs = [torch.randn(5, 6) for _ in range(3)]
+    m1, m2 = copy.deepcopy(base), copy.deepcopy(base)
+    bucket = dp.GradBucket(m1.parameters())
+    o1 = torch.optim.Adam(bucket.params, lr=1e-2)
+    o2 = torch.optim.Adam(m2.parameters(), lr=1e-2)
+    for x in xs:
+        l1 = dp.train_step(m1, bucket, o1, lambda y: (y ** 2).mean() * 100, (x,), clip=0.5)   # clip active
+        l2 = dp.train_step(m2, None, o2, lambda y: (y ** 2).mean() * 100, (x,), clip=0.5)
+        assert torch.allclose(l1, l2, rtol=1e-6, atol=1e-7)
+    for p, q in zip(m1.parameters(), m2.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-6)

@@ -236,3 +236,30 @@ def test_eval_mode_call_with_grad_enabled_warns(lss):
     lss.bevencode.eval()
     with pytest.warns(UserWarning, match="no_grad"), torch.enable_grad():
         lss.bevencode(torch.randn(1, 64, 16, 16))
+
+
+def test_batch_counters_are_collected_and_flushed_once():
+    """modules._count_batch: inside BevEncode.features the BatchNorm counters are collected and bumped by one foreach
+    call at the end; outside (stand-alone units) each is bumped at once; a failing forward leaves no collector behind."""
+    import torch
+
+    from lss2_multimodal_nu_amd import modules as M
+    bns = [torch.nn.BatchNorm2d(8) for _ in range(3)]
+    M._count_batch(bns[0])
+    assert int(bns[0].num_batches_tracked) == 1
+    outer, M._batch_counters[0] = M._batch_counters[0], []
+    try:
+        for bn in bns:
+            M._count_batch(bn)
+        assert [int(b.num_batches_tracked) for b in bns] == [1, 0, 0]   # nothing bumped yet
+        torch._foreach_add_(M._batch_counters[0], 1)
+    finally:
+        M._batch_counters[0] = outer
+    assert [int(b.num_batches_tracked) for b in bns] == [2, 1, 1]
+    be = M.BevEncode(64, 4)
+    be.train()
+    try:
+        be.features(torch.zeros(1, 3, 8, 8))   # wrong channel count: raises inside the collecting region
+    except Exception:
+        pass
+    assert M._batch_counters[0] is None
