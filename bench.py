@@ -446,10 +446,12 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     m = L.compile_model_lss(B, GRID, AUG, 4, precision=args.precision).to(dev).train()
     # N > 1: every p.grad is a view of one flat buffer and the bucket all-reduces start inside backward.
     # N = 1: the reference's loop as it stands (dp.train_step_local) - no flat buffer, no per-parameter `grad += g`
+    # One HIP graph per step when this is the only rank (dp.GraphedTrainStep; LSS_TRAIN_GRAPH=0: eager launches); under
+    # data parallelism the bucket all-reduces start from backward hooks and the step stays eager.
+    graph_env = os.environ.get("LSS_TRAIN_GRAPH", "1") != "0"
+    want_graph = graph_env and world == 1
     bucket = dp.make_bucket(m) if world > 1 else None
     params = bucket.params if bucket is not None else [p for p in m.parameters() if p.requires_grad]
-    # one HIP graph per step when this is the only rank (dp.GraphedTrainStep; LSS_TRAIN_GRAPH=0: eager launches)
-    want_graph = world == 1 and os.environ.get("LSS_TRAIN_GRAPH", "1") != "0"
     try:  # the fused single-kernel Adam (same update rule as train.py:42's torch.optim.Adam) where the build has it
         opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-8, capturable=want_graph, fused=True)
         adam = "fused"
@@ -481,7 +483,7 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     def one():  # ref: train.py:49-66 (zero_grad, forward, loss, backward, clip 5.0, Adam) + the DP all-reduce
         dp.train_step(wrapped, bucket, opt, loss_fn, (feats,) + tuple(calib), clip=5.0)
 
-    graph_note = "eager launches (%s)" % ("world_size > 1" if world > 1 else "LSS_TRAIN_GRAPH=0")
+    graph_note = "eager launches (%s)" % ("LSS_TRAIN_GRAPH=0" if not graph_env else "world_size > 1: bucket all-reduces start inside backward")
     if want_graph:
         try:
             graphed = dp.GraphedTrainStep(wrapped, bucket, opt, loss_fn, feats, tuple(calib), clip=5.0, warmup=5)

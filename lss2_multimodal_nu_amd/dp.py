@@ -279,11 +279,21 @@ class GraphedTrainStep:
     the eager step is host-bound once the weight-gradient kernels are fast).
 
     Everything a step reads from outside lives in STATIC device buffers that `__call__` refreshes before the
-    replay: the feature tensor, the targets the loss function closes over (pass them as `extra_static` pairs
-    `(static_device_tensor, new_value)` through `__call__(..., refresh=...)`), and the calibration as a
-    device-resident `CalibrationPack` (host inverses as always, data.prepare_calibration; one H2D copy per step).
-    The optimizer must be built with `capturable=True`.  Single process only: with world_size > 1 the bucket
-    all-reduce is a cross-stream RCCL launch and the step stays eager (`train_step`)."""
+    replay: the feature tensor, the targets the loss function closes over (pass them as `(static_device_tensor,
+    new_value)` pairs through `__call__(..., refresh=...)`), and the calibration as a device-resident
+    `CalibrationPack` (host inverses as always, data.prepare_calibration; one H2D copy per step).  The optimizer
+    must be built with `capturable=True`.
+
+    After capture the step is replayed three times on the capture inputs and the gradients it leaves are checked
+    (`_self_check`): a library kernel that is not safe inside a graph shows up there (MIOpen's weight-gradient
+    solvers were: modules.conv_s2_backward_gemm).
+
+    Single process only.  Under data parallelism the bucket all-reduces are cross-stream launches of the
+    communication library started from backward hooks; a variant with [zero, forward, backward] as a graph and
+    collective + clip + Adam behind it ran clean on one process but left one wild gradient element in a 2-rank gloo
+    run on a shared GPU, could not be tried on RCCL here, and is not shipped: `train_step` stays eager there."""
+
+    CHECK_REPLAYS = 3  # replays of the self-check after capture (ordinary steps on the capture inputs)
 
     def __init__(self, model, bucket, opt, loss_fn, feats, calib, clip=5.0, warmup=3):
         from .data import CalibrationPack, prepare_calibration
@@ -296,6 +306,7 @@ class GraphedTrainStep:
         host = calib if isinstance(calib, CalibrationPack) else prepare_calibration(*calib)
         self.pack = CalibrationPack(host.buffer.to(feats.device), host.shape)
         self._inputs = (self.feats, self.pack, None, None, None, None)
+        self._params = [p for g in opt.param_groups for p in g["params"]]
 
         def step():
             return train_step(model, bucket, opt, loss_fn, self._inputs, clip=clip)
@@ -311,6 +322,27 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = step()
+        self._self_check()
+
+    def _grad_norm(self):
+        gs = [p.grad for p in self._params if p.grad is not None]
+        return float(torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g.float()) for g in gs])))
+
+    def _self_check(self):
+        """Replay the captured step three times on the inputs it was captured with and look at the (clipped)
+        gradients it leaves: a kernel that accumulates into a buffer which is only cleared outside the captured
+        stream shows up as gradients that explode, vanish or go non-finite from the second replay on - seen with
+        MIOpen's weight-gradient solvers: 1e30 in one tensor, which the clip then turned into an all-zero gradient
+        while Adam's momentum kept the loss moving.  (The replays are ordinary training steps: extra warm-up.)"""
+        norms = []
+        for _ in range(self.CHECK_REPLAYS):
+            self.graph.replay()
+            torch.cuda.synchronize()
+            norms.append(self._grad_norm())
+        ok = all(n == n and 0.0 < n < float("inf") for n in norms) and max(norms) <= 20.0 * min(norms)
+        if not ok:
+            raise RuntimeError("replayed gradients are not stable (norms %s): something in the step is not graph-safe"
+                               % (", ".join("%.3g" % n for n in norms),))
 
     def __call__(self, feats, calib, refresh=()):
         """One step on new inputs; returns the (static) loss tensor.  `refresh`: (static_tensor, new_value) pairs

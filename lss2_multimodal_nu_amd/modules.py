@@ -95,11 +95,65 @@ class _Conv3x3Fn(torch.autograd.Function):
         return gx, gw
 
 
+def conv_s2_backward_gemm(g, x, weight, pad, need_x=True, need_w=True):
+    """Both gradients of a bias-free stride-2 conv as im2col + GEMM + col2im (ATen `unfold` / `matmul` / `fold`):
+    g (B,Co,Ho,Wo), x (B,C,H,W), weight (Co,C,K,K) -> (gx like x or None, gw (Co,C,K,K) fp32 or None).
+    Used instead of the library's `convolution_backward` because MIOpen's weight-gradient solvers are not safe
+    inside a HIP graph on this stack: the captured step replayed garbage (1e30) into `layer3.0.conv1.weight.grad`
+    from the second replay on (an accumulation buffer that is only cleared outside the captured stream), and with
+    `cudnn.deterministic` every gradient - found by replaying the forward + backward half alone and looking at the
+    gradients.  GEMMs and the two layout kernels replay exactly."""
+    B, C, H, W = x.shape
+    Co, _, K, _ = weight.shape
+    L = g.shape[2] * g.shape[3]
+    g2 = g.reshape(B, Co, L)
+    gx = gw = None
+    if need_w:
+        cols = F.unfold(x, K, padding=pad, stride=2)                      # (B, C*K*K, L)
+        # one batched GEMM over the samples, summed in fp32 (no (C*K*K, B*L) copy of the columns: 250 MB at the stem)
+        gw = torch.bmm(g2, cols.transpose(1, 2)).float().sum(0).view(Co, C, K, K)
+    if need_x:
+        colsg = torch.matmul(weight.reshape(Co, C * K * K).t().to(g.dtype), g2)   # (B, C*K*K, L)
+        gx = F.fold(colsg, (H, W), K, padding=pad, stride=2)
+    return gx, gw
+
+
+_s2_tap_index = {}
+
+
+def conv_s2_wgrad_phase_planes(xn, gyn, K):
+    """Weight gradient of a bias-free stride-2 conv with K in {1, 3} (pad K // 2) on K9w (csrc/conv_wgrad.hip): in
+    phase planes xs[b, y, x, (py, px, c)] = x[b, 2y + py, 2x + px, c] the conv is a stride-1 conv with taps
+    (dy, dx) in {-1, 0}^2, i.e. a sub-set of the 3x3 / pad 1 weight gradient of (xs, dy) that K9w computes:
+    input row 2 oy + ky - 1 = 2 (oy + dy) + py gives ky = 0 -> (dy -1, py 1), ky = 1 -> (0, 0), ky = 2 -> (0, 1);
+    the 1x1 / 2 conv is the centre tap of phase (0, 0).  (5 of the 9 taps K9w computes are not used: these are the
+    two smallest weight gradients of the step.)  xn (B,H,W,C), gyn (B,H/2,W/2,Co) bf16 NHWC -> (Co,C,K,K) fp32."""
+    B, H, W, C = xn.shape
+    Co = gyn.shape[3]
+    xs = xn.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // 2, W // 2, 4 * C)
+    g6 = ops.conv3x3_wgrad(xs, gyn).view(Co, 2, 2, C, 3, 3)   # [co][py][px][ci][ty][tx], tap t = d + 1
+    if K == 1:
+        return g6[:, 0, 0, :, 1, 1].reshape(Co, C, 1, 1).contiguous()
+    key = str(xn.device)
+    idx = _s2_tap_index.get(key)
+    if idx is None:  # built once per device (outside any graph capture: the first call is a warm-up step)
+        idx = _s2_tap_index[key] = (torch.tensor([1, 0, 1], device=xn.device), torch.tensor([0, 1, 1], device=xn.device))
+    ph, tp = idx
+    # advanced indices separated by a slice: the broadcast (ky, kx) dimensions come first
+    return g6[:, ph[:, None], ph[None, :], :, tp[:, None], tp[None, :]].permute(2, 3, 0, 1).contiguous()
+
+
+def _s2_wgrad_native_ok(xn, Co, K):
+    B, H, W, C = xn.shape
+    return (xn.is_cuda and K in (1, 3) and H % 2 == 0 and W % 2 == 0 and (4 * C) % 64 == 0 and Co % 64 == 0
+            and 8 <= W // 2 <= 224 and os.environ.get("LSS_S2_WGRAD_GEMM") != "1")
+
+
 class _ConvS2Fn(torch.autograd.Function):
     """Bias-free stride-2 conv (the 7x7 / 2 stem, the 3x3 / 2 first convs and the 1x1 / 2 shortcuts of layer2 / layer3;
     ref src/modules.py:99 + torchvision BasicBlock) with the FORWARD on the same K8 phase-plane kernel as inference
-    (bf16 NHWC, fp32 accumulation); the two gradients are the library's convolution_backward on the saved bf16
-    operands (5 small layers: 8 % of a training step - DESIGN.md section 9)."""
+    (bf16 NHWC, fp32 accumulation); the two gradients are im2col + GEMM + col2im on the saved bf16 operands
+    (`conv_s2_backward_gemm`: 5 small layers; graph-safe, which the library's convolution_backward is not)."""
 
     @staticmethod
     def forward(ctx, x, weight, pad):
@@ -120,10 +174,25 @@ class _ConvS2Fn(torch.autograd.Function):
         xn, weight = ctx.saved_tensors
         x_dtype, pad = ctx.cfg
         g = gy if gy.dtype == torch.bfloat16 else gy.to(torch.bfloat16)
-        gx, gw, _ = torch.ops.aten.convolution_backward(
-            g.contiguous(memory_format=torch.channels_last), xn.permute(0, 3, 1, 2), weight.detach().to(torch.bfloat16),
-            None, [2, 2], [pad, pad], [1, 1], False, [0, 0], 1,
-            [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
+        x = xn.permute(0, 3, 1, 2)
+        gx = gw = None
+        if ctx.needs_input_grad[1]:
+            # the WEIGHT gradient never goes to the library: its solvers are the ones that broke graph replays.
+            # 3x3 / 2 and 1x1 / 2: K9w over phase planes; the 7x7 / 2 stem (taps dy in {-2 .. 1}): im2col + GEMM
+            K = weight.shape[2]
+            if _s2_wgrad_native_ok(xn, weight.shape[0], K):
+                gw = conv_s2_wgrad_phase_planes(xn, g.permute(0, 2, 3, 1).contiguous(), K)
+            else:
+                _, gw = conv_s2_backward_gemm(g.contiguous(), x, weight.detach(), pad, need_x=False)
+        if ctx.needs_input_grad[0]:
+            if x.is_cuda and os.environ.get("LSS_S2_DGRAD_GEMM") != "1":
+                # data gradient: the library's transposed-conv kernels (no accumulation buffers; replay-checked by
+                # dp.GraphedTrainStep._self_check and tests/test_dp_gpu.py on every replay); 4x cheaper than col2im
+                gx = torch.ops.aten.convolution_backward(
+                    g.contiguous(memory_format=torch.channels_last), x, weight.detach().to(torch.bfloat16), None,
+                    [2, 2], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            else:
+                gx, _ = conv_s2_backward_gemm(g.contiguous(), x, weight.detach(), pad, need_w=False)
         return (None if gx is None else gx.to(x_dtype), None if gw is None else gw.to(weight.dtype), None)
 
 

@@ -199,3 +199,24 @@ def test_bn_train_statistics_of_large_mean_channels():
     # constant channel: y = z * scale + shift with the folded (scale, shift) = (316, -316 000): one fp32 rounding of a
     # 3e5-sized product is what is left (torch's (z - mean) * invstd form gives exactly 0)
     assert float(yn[:, 3].abs().max()) < 0.05
+
+
+@pytest.mark.parametrize("cfg", [(3, 4, 100, 100, 64, 128), (3, 2, 50, 50, 128, 256), (1, 4, 100, 100, 64, 128),
+                                 (1, 2, 50, 50, 128, 256), (3, 1, 36, 44, 64, 64)])
+def test_stride2_wgrad_over_phase_planes_vs_torch(cfg):
+    """modules.conv_s2_wgrad_phase_planes (K9w on the space-to-depth input + tap / phase selection) against torch's
+    weight gradient of the stride-2 conv on the same bf16 operands - the 3x3 / 2 convs and 1x1 / 2 shortcuts of
+    layer2.0 / layer3.0 (torchvision BasicBlock; ref src/modules.py:104-106) - and against the im2col + GEMM form."""
+    from lss2_multimodal_nu_amd import modules as M
+    K, B, H, W, C, Co = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(B, H, W, C, generator=g).bfloat16()
+    dy = torch.randn(B, H // 2, W // 2, Co, generator=g).bfloat16()
+    ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (Co, C, K, K), dy.float().permute(0, 3, 1, 2),
+                                      stride=2, padding=K // 2)
+    gw = M.conv_s2_wgrad_phase_planes(x.cuda(), dy.cuda(), K)
+    assert gw.shape == ref.shape and gw.dtype == torch.float32
+    assert float((gw.cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+    _, gw2 = M.conv_s2_backward_gemm(dy.cuda().permute(0, 3, 1, 2), x.cuda().permute(0, 3, 1, 2),
+                                     torch.zeros(Co, C, K, K, device="cuda"), K // 2, need_x=False)
+    assert float((gw2.cpu() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())   # bf16 products of the batched GEMM
