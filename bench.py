@@ -519,7 +519,9 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
             "note": "lift-splat fwd/bwd native HIP (fp32); under bf16 autocast every 3x3/s1 conv + BatchNorm(train) + "
                     "residual + ReLU unit of BevEncode (95 % of its FLOPs) is one HIP autograd node: conv fwd / dgrad / "
                     "wgrad, BN fwd / bwd, fused upsample+concat and its adjoint (LSS_TRAIN_NATIVE=0 = library path for "
-                    "A/B); the 7x7/2 stem, the stride-2 and 1x1 convs and Adam are torch / MIOpen ops; 1x1 head + weighted cross-entropy = one HIP kernel per direction"}
+                    "A/B); the 7x7/2 stem, the 3x3/2 convs and the 1x1/2 shortcuts run forward, dgrad and wgrad on the same HIP kernels "
+                    "over phase planes; 1x1 head + weighted cross-entropy = one HIP kernel per direction; library ops left: the two "
+                    "fp32 depthnet GEMMs of the lift-splat backward, Adam (fused), clip"}
 
 
 def host_cores():

@@ -315,6 +315,23 @@ size_t lss_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int lss_conv2d_wgrad(const void* x, const void* dy, int B, int H, int W, int Cin, int Cout,
                      void* workspace, size_t workspace_bytes, float* dw_oihw, void* stream);
 int lss_conv2d_wgrad_timeouts(void);
+/* Weight gradient of the 4 x 4-tap stride-1 conv with taps (dy, dx) in {-2 .. 1}^2 on K9w (two launches of eight
+ * consumer waves): what the 7x7 / stride-2 / pad-3 stem conv (ref src/modules.py:99, its ConvolutionBackward under
+ * train.py:61) is over the phase planes xs[b, y, x, (py, px, c)] = x[b, 2y + py, 2x + px, c].
+ *   xs (B,H,W,Cin) bf16 NHWC (Cin = 4 x the conv's input channels), dy (B,H,W,Cout) bf16 NHWC;
+ *   dw16 (Cout, Cin, 16) fp32, tap index (dy + 2) * 4 + dx + 2, fully overwritten; fixed summation order.
+ *   Same shape rules as K9w (Cin % 64 == 0, Cout % 64 == 0, 8 <= W <= 224); LSS_E_SHAPE otherwise. */
+/* Data gradient of the stride-2 convs (7x7 / pad 3 stem, 3x3 / pad 1, 1x1 / pad 0 shortcut; ref src/modules.py:99 and
+ * torchvision BasicBlock, their ConvolutionBackward under train.py:61) as ONE stride-1 conv over dY that yields the
+ * input's four phase planes: lss_conv2d_s2_dgrad_taps(K, pad) = taps per dimension KT (4 / 2 / 1; 0: not a case);
+ * lss_conv2d_pack_weights_s2_dgrad arranges w [Cout][Cin][K][K] as bf16 [KT*KT][4*Cin][Cout]; then
+ * lss_conv2d_fwd(dy, ..., Cx = Cout, Cout = 4*Cin, KH = KW = KT, stride 1, pad KT/2) and rows / columns [s, s + H/2)
+ * of its output (s = 1 for KT = 2, 4; 0 for KT = 1) are dXs[b, j, i, (py, px, ci)] = dX[b, 2j + py, 2i + px, ci]. */
+int lss_conv2d_s2_dgrad_taps(int K, int pad);
+int lss_conv2d_pack_weights_s2_dgrad(const float* w_oihw, int Cout, int Cin, int K, int pad, void* w_packed, void* stream);
+size_t lss_conv2d_wgrad4x4_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int lss_conv2d_wgrad4x4(const void* xs, const void* dy, int B, int H, int W, int Cin, int Cout,
+                        void* workspace, size_t workspace_bytes, float* dw16, void* stream);
 
 /* Backward helpers of the fused upsample + concat conv input (ref Up.forward, src/modules.py:22-24;
  * bf16 NHWC).  lss_upsample_cat_nhwc materialises [x2 | bilinear_align_corners(x, up)] as

@@ -53,6 +53,10 @@ SIGNATURES = {
     "lss_conv2d_pack_weights_dgrad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lss_conv2d_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "lss_conv2d_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "lss_conv2d_wgrad4x4_workspace_bytes": (_sz, [_i] * 5),
+    "lss_conv2d_s2_dgrad_taps": (_i, [_i, _i]),
+    "lss_conv2d_pack_weights_s2_dgrad": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "lss_conv2d_wgrad4x4": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "lss_upsample_cat_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "lss_upsample_bwd_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "lss_bn_train_workspace_bytes": (_sz, [ctypes.c_longlong, _i]),

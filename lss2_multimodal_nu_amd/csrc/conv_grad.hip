@@ -25,6 +25,8 @@ int lss_wgrad_gemm_launch(const void* dyt, const void* const xt[3], float* parti
 int lss_wgrad_direct_splits(int B, int H, int W, int Cin, int Cout);
 int lss_wgrad_direct_launch(const void* x, const void* dy, int B, int H, int W, int Cin, int Cout, float* partial,
                             hipStream_t st);
+int lss_wgrad_taps4x4_launch(const void* x, const void* dy, int B, int H, int W, int Cin, int Cout, float* partial,
+                             hipStream_t st);
 
 namespace {
 
@@ -43,6 +45,26 @@ __global__ void pack_weights_dgrad_kernel(const float* __restrict__ w, int Cout,
     const float v = w[(((size_t)co * Cin + ci) * KH + ky) * KW + kx];
     if (sizeof(T) == 2) reinterpret_cast<unsigned short*>(out)[e] = lss_f2bf(v);
     else reinterpret_cast<float*>(out)[e] = v;
+  }
+}
+
+// Data gradient of a stride-2 K x K conv (pad p) as a stride-1 conv over dY that produces the input's four PHASE
+// PLANES at once: dX[2j + py] = sum_d dY[j - d] * w[ky = 2d + py + p].  d runs over [dmin, dmax] = [ceil((-1 - p) / 2),
+// floor((K - 1 - p) / 2)] (3x3 / p1: {-1, 0}; 7x7 / p3: {-2 .. 1}; 1x1 / p0: {0}), tap t of the KT = dmax - dmin + 1 taps
+// per dimension reads dY[j - dmax + t], i.e. d = dmax - t.  Packed as [tap][Cout' = (py, px, ci)][Cin' = co], zeros
+// where ky or kx falls outside the kernel.
+__global__ void pack_weights_s2_dgrad_kernel(const float* __restrict__ w, int Cout, int Cin, int K, int pad, int KT,
+                                             int dmax, unsigned short* __restrict__ out) {
+  const size_t n = (size_t)KT * KT * 4 * Cin * Cout;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int co = e % Cout;
+    size_t r = e / Cout;
+    const int ci = r % Cin; r /= Cin;
+    const int px = r & 1, py = (r >> 1) & 1; r >>= 2;
+    const int tx = r % KT, ty = r / KT;
+    const int ky = 2 * (dmax - ty) + py + pad, kx = 2 * (dmax - tx) + px + pad;
+    const bool ok = ky >= 0 && ky < K && kx >= 0 && kx < K;
+    out[e] = ok ? lss_f2bf(w[(((size_t)co * Cin + ci) * K + ky) * K + kx]) : (unsigned short)0;
   }
 }
 
@@ -146,10 +168,10 @@ __global__ __launch_bounds__(256) void to_channel_major_kernel(const unsigned sh
   }
 }
 
-// dW (OIHW fp32) = sum over splits, in split order
+// dW ([Cout][Cin][ntap] fp32: OIHW for the 3x3 conv) = sum over splits, in split order
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int Cout, int Cin,
-                                    float* __restrict__ dw) {
-  const size_t n = (size_t)9 * Cout * Cin;
+                                    float* __restrict__ dw, int ntap) {
+  const size_t n = (size_t)ntap * Cout * Cin;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
     const int ci = e % Cin;
     const size_t t = e / Cin;
@@ -166,7 +188,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
       s3 += partial[(size_t)(k + 3) * n + e];
     }
     for (; k < nsplit; ++k) s0 += partial[(size_t)k * n + e];
-    dw[((size_t)co * Cin + ci) * 9 + tap] = (s0 + s1) + (s2 + s3);
+    dw[((size_t)co * Cin + ci) * ntap + tap] = (s0 + s1) + (s2 + s3);
   }
 }
 
@@ -281,6 +303,29 @@ extern "C" int lss_conv2d_pack_weights_dgrad(const float* w_oihw, int Cout, int 
   return lss_launch_status();
 }
 
+// taps per dimension of the phase-plane data-gradient conv of a stride-2 K x K / pad conv (0: not a case)
+extern "C" int lss_conv2d_s2_dgrad_taps(int K, int pad) {
+  if (!((K == 1 && pad == 0) || (K == 3 && pad == 1) || (K == 7 && pad == 3))) return 0;
+  return K == 1 ? 1 : (K == 3 ? 2 : 4);
+}
+
+// w_oihw [Cout][Cin][K][K] fp32 -> bf16 [KT*KT][4*Cin][Cout]: use with lss_conv2d_fwd(dy, ..., Cx = Cout,
+// Cout = 4 * Cin, KH = KW = KT, stride 1, pad KT / 2); rows / columns [s, s + H/2) of its output (s = 1 for KT = 2, 4;
+// 0 for KT = 1) are the phase planes dXs[b, j, i, (py, px, ci)] = dX[b, 2j + py, 2i + px, ci].
+extern "C" int lss_conv2d_pack_weights_s2_dgrad(const float* w_oihw, int Cout, int Cin, int K, int pad,
+                                                void* w_packed, void* stream) {
+  LSS_CHECK_PTR(w_oihw); LSS_CHECK_PTR(w_packed);
+  LSS_CHECK_POS(Cout); LSS_CHECK_POS(Cin);
+  const int KT = lss_conv2d_s2_dgrad_taps(K, pad);
+  if (KT == 0) return LSS_E_SHAPE;
+  const int dmax = (K - 1 - pad) / 2;
+  const size_t n = (size_t)KT * KT * 4 * Cin * Cout;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(pack_weights_s2_dgrad_kernel, dim3(grid), dim3(256), 0, lss_stream(stream), w_oihw, Cout, Cin, K,
+                     pad, KT, dmax, reinterpret_cast<unsigned short*>(w_packed));
+  return lss_launch_status();
+}
+
 extern "C" size_t lss_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
   const int nd = lss_wgrad_direct_splits(B, H, W, Cin, Cout);
@@ -305,7 +350,7 @@ extern "C" int lss_conv2d_wgrad(const void* x, const void* dy, int B, int H, int
     if (rc != 0) return rc;
     const size_t n = (size_t)9 * Cout * Cin;
     const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, partial, nd, Cout, Cin, dw_oihw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, partial, nd, Cout, Cin, dw_oihw, 9);
     return lss_launch_status();
   }
   const WgradGeom g = wgrad_geom(B, H, W, Cin, Cout);
@@ -327,7 +372,33 @@ extern "C" int lss_conv2d_wgrad(const void* x, const void* dy, int B, int H, int
   if (rc != 0) return rc;
   const size_t n = (size_t)9 * Cout * Cin;
   const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, partial, g.nsplit, Cout, Cin, dw_oihw);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, partial, g.nsplit, Cout, Cin, dw_oihw, 9);
+  return lss_launch_status();
+}
+
+// Weight gradient of the 4 x 4-tap stride-1 conv with taps (dy, dx) in {-2 .. 1}^2 - what a 7x7 / stride-2 / pad-3
+// conv (the BevEncode stem, ref src/modules.py:99) is over the phase planes xs[b, y, x, (py, px, c)] =
+// x[b, 2y + py, 2x + px, c]: dw16[co][ci'][(dy + 2) * 4 + dx + 2] = sum dY[b,y,x,co] * xs[b, y + dy, x + dx, ci'].
+extern "C" size_t lss_conv2d_wgrad4x4_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  const int nd = lss_wgrad_direct_splits(B, H, W, Cin, Cout);
+  return nd > 0 ? align256((size_t)nd * 16 * Cout * Cin * 4) : 0;
+}
+
+extern "C" int lss_conv2d_wgrad4x4(const void* xs, const void* dy, int B, int H, int W, int Cin, int Cout,
+                                   void* workspace, size_t workspace_bytes, float* dw16, void* stream) {
+  LSS_CHECK_PTR(xs); LSS_CHECK_PTR(dy); LSS_CHECK_PTR(workspace); LSS_CHECK_PTR(dw16);
+  LSS_CHECK_POS(B); LSS_CHECK_POS(H); LSS_CHECK_POS(W); LSS_CHECK_POS(Cin); LSS_CHECK_POS(Cout);
+  const int nd = lss_wgrad_direct_splits(B, H, W, Cin, Cout);
+  if (nd <= 0) return LSS_E_SHAPE;
+  if (workspace_bytes < lss_conv2d_wgrad4x4_workspace_bytes(B, H, W, Cin, Cout)) return LSS_E_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return LSS_E_ALIGN;
+  hipStream_t st = lss_stream(stream);
+  float* partial = static_cast<float*>(workspace);
+  int rc = lss_wgrad_taps4x4_launch(xs, dy, B, H, W, Cin, Cout, partial, st);
+  if (rc != 0) return rc;
+  const size_t n = (size_t)16 * Cout * Cin;
+  const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, partial, nd, Cout, Cin, dw16, 16);
   return lss_launch_status();
 }
 

@@ -1265,6 +1265,14 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
     else launch_conv_lds<0, 3, 3, 1>(a, st);
     return lss_launch_status();
   }
+  // 2x2 / pad 1 and 4x4 / pad 2, stride 1: the data gradients of the 3x3 / 2 and 7x7 / 2 convs over phase planes
+  // (lss_conv2d_pack_weights_s2_dgrad) - same tile kernel, other tap counts
+  if (dt == LSS_DT_BF16 && stride == 1 && !fused && KH == KW && a.Cin % 64 == 0 && a.stats == nullptr &&
+      ((KH == 2 && pad == 1) || (KH == 4 && pad == 2)) && getenv("LSS_CONV_DIRECT") == nullptr) {
+    if (KH == 2) launch_conv_lds<0, 2, 2, 1>(a, st);
+    else launch_conv_lds<0, 4, 4, 2>(a, st);
+    return lss_launch_status();
+  }
   // 1x1 / stride 1: the token-major linear layers of the BEV transformer and the 1x1 convs
   // a 1x1 / stride-1 conv over NHWC is a row-major GEMM over the B*H*W pixel rows
   // (linear_mfma.hip): the token-major linear layers of the BEV transformer and the 1x1

@@ -35,7 +35,7 @@ __device__ int lss_wgrad_timeouts;  // flag waits that hit their bound (must sta
 
 constexpr int WK_NDB = 10;          // dY ring: K blocks
 constexpr int WK_BLK = 32 * 128;    // 4096 B: 32 positions x 64 channels
-constexpr int WK_NCONS = 9, WK_NXL = 2, WK_NWAVES = 12;
+constexpr int WK_NXL = 2;            // X loader waves
 constexpr int WK_MAXKB = 7;         // K blocks per row (W <= 224)
 constexpr int WK_MAXXS = 8;         // X row slots
 constexpr int WK_LDS_MAX = 160 * 1024;
@@ -52,6 +52,8 @@ struct WgradArgs {
   int xs_bytes;    // bytes of a slot: (32 KB + 8) positions x 128
   int rows_total;  // B * (H + 2) padded rows
   int rows_per;    // padded rows per split
+  int ntap_total;  // taps of the partial tile array (9, or 16 for the two-launch 4x4 form)
+  int tap_base;    // first tap this launch writes
 };
 
 __device__ __attribute__((aligned(128))) unsigned char lss_wgrad_zero_page[128];
@@ -72,7 +74,14 @@ __device__ __forceinline__ wk_bf16x8 wk_frag(const unsigned char* lo, const unsi
   const wk_s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
   return __builtin_bit_cast(wk_bf16x8, v);
 }
-__global__ __launch_bounds__(WK_NWAVES * 64) void conv_wgrad_kernel(const WgradArgs a) {
+// Tap grid of one launch: NTY x NTX taps (one consumer wave each, <= 9), tap (ty, tx) = displacement (DY0 + ty,
+// tx - LP): the X row image keeps LP zero positions in front of x = 0, so a tap reads position (pixel + tx).
+// <3, 3, -1, 1>: the 3x3 / pad-1 conv.  <2, 4, -2, 2> + <2, 4, 0, 2>: the 4x4 taps {-2 .. 1}^2 of a 7x7 / 2 / pad-3
+// conv over phase planes, as two launches of eight consumers (two per SIMD).
+template <int NTY, int NTX, int DY0, int LP>
+__global__ __launch_bounds__((NTY * NTX + 1 + WK_NXL) * 64) void conv_wgrad_kernel(const WgradArgs a) {
+  constexpr int WK_NCONS = NTY * NTX;
+  static_assert(WK_NCONS <= 9 && NTX + LP <= 8, "tap grid");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -99,20 +108,20 @@ __global__ __launch_bounds__(WK_NWAVES * 64) void conv_wgrad_kernel(const WgradA
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
       const int i = wl + k * WK_NXL;
-      const int idx = 8 * i + (lane >> 3), x = idx - 1;
+      const int idx = 8 * i + (lane >> 3), x = idx - LP;
       const int sb = (lane & 7) >> 1, half = lane & 1;
       const int ch = ci0 + ((sb ^ wk_swz(idx)) << 4) + half * 8;
       xoff[k] = (i < npieces && x >= 0 && x < a.W) ? x * a.Cin + ch : -1;
     }
     const unsigned char* zsrc = lss_wgrad_zero_page + (lane & 7) * 16;
     int slot = 0, uses = 0;
-    for (int k = 0; k < ntile + 2; ++k) {
+    for (int k = 0; k < ntile + NTY - 1; ++k) {
       // slot `slot` last held row k - nxs: every consumer releases every row once (the taps of row ky use it at tile
       // k - ky; a wave that never uses one of the first rows releases it at start-up), so `uses` x 9 releases free it.
       // A single "tiles done" counter would not do: the consumers drift by up to the dY ring's depth, and eight waves
       // two tiles ahead would add up to the count that was meant to say "all nine have finished".
       if (uses > 0) rk_wait_ge<4>(flags + F_FREE_X + slot, WK_NCONS * uses);
-      const int rho = pi0 - 1 + k;
+      const int rho = pi0 + DY0 + k;
       const bool inr = rho >= 0 && rho < a.rows_total;
       const int b = inr ? rho / HP : 0, yp = inr ? rho - b * HP : 0;
       const bool real = inr && yp >= 1 && yp <= a.H;
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(WK_NWAVES * 64) void conv_wgrad_kernel(const WgradA
   }
 
   // ======================================= consumers: one tap each =======================================
-  const int ky = wave / 3, kx = wave - 3 * ky;
+  const int ky = wave / NTX, kx = wave - NTX * ky;  // (ty, tx) of this wave's tap
   const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
   int aoff[2][4], boff[2][4];
 #pragma unroll
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(WK_NWAVES * 64) void conv_wgrad_kernel(const WgradA
 
   // partial[split][tap][co][ci]: lane (g, n = lane & 15) holds rows 4 g + i, column n of every 16 x 16 tile
   const int n = lane & 15;
-  float* out = a.partial + ((size_t)split * 9 + wave) * a.Cout * a.Cin + (size_t)co0 * a.Cin + ci0;
+  float* out = a.partial + ((size_t)split * a.ntap_total + a.tap_base + wave) * a.Cout * a.Cin + (size_t)co0 * a.Cin + ci0;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -288,26 +297,57 @@ int lss_wgrad_direct_splits(int B, int H, int W, int Cin, int Cout) {
   return p.ok ? p.nsplit : 0;
 }
 
-int lss_wgrad_direct_launch(const void* x, const void* dy, int B, int H, int W, int Cin, int Cout, float* partial,
-                            hipStream_t st) {
-  const WgradPlan p = wgrad_plan(B, H, W, Cin, Cout);
-  if (!p.ok) return LSS_E_SHAPE;
-  static bool attr_set = false;
+namespace {
+
+template <int NTY, int NTX, int DY0, int LP>
+int launch_taps(const WgradPlan& p, WgradArgs& a, hipStream_t st) {
+  static bool attr_set = false;  // per instantiation
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<NTY, NTX, DY0, LP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WK_LDS_MAX);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
+  const int grid = (a.Cin / 64) * (a.Cout / 64) * p.nsplit;
+  hipLaunchKernelGGL((conv_wgrad_kernel<NTY, NTX, DY0, LP>), dim3(grid), dim3((NTY * NTX + 1 + WK_NXL) * 64), p.lds, st, a);
+  return lss_launch_status();
+}
+
+WgradArgs wgrad_args(const WgradPlan& p, const void* x, const void* dy, int B, int H, int W, int Cin, int Cout,
+                     float* partial) {
   WgradArgs a;
   a.x = static_cast<const unsigned short*>(x);
   a.dy = static_cast<const unsigned short*>(dy);
   a.partial = partial;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.KB = p.KB; a.nxs = p.nxs; a.xs_bytes = p.xs_bytes; a.rows_total = p.rows_total; a.rows_per = p.rows_per;
-  const int grid = (Cin / 64) * (Cout / 64) * p.nsplit;
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(grid), dim3(WK_NWAVES * 64), p.lds, st, a);
-  return lss_launch_status();
+  a.ntap_total = 9; a.tap_base = 0;
+  return a;
+}
+
+}  // namespace
+
+int lss_wgrad_direct_launch(const void* x, const void* dy, int B, int H, int W, int Cin, int Cout, float* partial,
+                            hipStream_t st) {
+  const WgradPlan p = wgrad_plan(B, H, W, Cin, Cout);
+  if (!p.ok) return LSS_E_SHAPE;
+  WgradArgs a = wgrad_args(p, x, dy, B, H, W, Cin, Cout, partial);
+  return launch_taps<3, 3, -1, 1>(p, a, st);
+}
+
+// The 4 x 4 taps (dy, dx) in {-2 .. 1}^2 (tap index (dy + 2) * 4 + dx + 2): the phase-plane form of a 7x7 / stride-2 /
+// pad-3 conv.  Two launches of eight consumer waves (rows dy = -2, -1 and dy = 0, 1) into partial[split][16][Cout][Cin].
+int lss_wgrad_taps4x4_launch(const void* x, const void* dy, int B, int H, int W, int Cin, int Cout, float* partial,
+                             hipStream_t st) {
+  const WgradPlan p = wgrad_plan(B, H, W, Cin, Cout);
+  if (!p.ok) return LSS_E_SHAPE;
+  WgradArgs a = wgrad_args(p, x, dy, B, H, W, Cin, Cout, partial);
+  a.ntap_total = 16;
+  a.tap_base = 0;
+  int rc = launch_taps<2, 4, -2, 2>(p, a, st);
+  if (rc != 0) return rc;
+  a.tap_base = 8;
+  return launch_taps<2, 4, 0, 2>(p, a, st);
 }
 
 extern "C" int lss_conv2d_wgrad_timeouts(void) {

@@ -122,7 +122,7 @@ _s2_tap_index = {}
 
 
 def conv_s2_wgrad_phase_planes(xn, gyn, K):
-    """Weight gradient of a bias-free stride-2 conv with K in {1, 3} (pad K // 2) on K9w (csrc/conv_wgrad.hip): in
+    """Weight gradient of a bias-free stride-2 conv with K in {1, 3, 7} (pad K // 2) on K9w (csrc/conv_wgrad.hip): in
     phase planes xs[b, y, x, (py, px, c)] = x[b, 2y + py, 2x + px, c] the conv is a stride-1 conv with taps
     (dy, dx) in {-1, 0}^2, i.e. a sub-set of the 3x3 / pad 1 weight gradient of (xs, dy) that K9w computes:
     input row 2 oy + ky - 1 = 2 (oy + dy) + py gives ky = 0 -> (dy -1, py 1), ky = 1 -> (0, 0), ky = 2 -> (0, 1);
@@ -131,29 +131,58 @@ def conv_s2_wgrad_phase_planes(xn, gyn, K):
     B, H, W, C = xn.shape
     Co = gyn.shape[3]
     xs = xn.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // 2, W // 2, 4 * C)
+    key = (str(xn.device), K)
+    idx = _s2_tap_index.get(key)
+    if idx is None:  # built once per device (outside any graph capture: the first call is a warm-up step)
+        # kernel row k reads input row 2 oy + k - K // 2 = 2 (oy + d) + p: phase p and tap index t = d - d_min
+        ds = [(k - K // 2) // 2 for k in range(K)]
+        idx = _s2_tap_index[key] = (torch.tensor([(k - K // 2) % 2 for k in range(K)], device=xn.device),
+                                    torch.tensor([d - min(ds) for d in ds], device=xn.device))
+    ph, tp = idx
+    if K == 7:  # the stem: taps d in {-2 .. 1} -> the 4x4-tap form of K9w (two launches of eight consumer waves)
+        g6 = ops.conv4x4_wgrad(xs, gyn).view(Co, 2, 2, C, 4, 4)
+        return g6[:, ph[:, None], ph[None, :], :, tp[:, None], tp[None, :]].permute(2, 3, 0, 1).contiguous()
     g6 = ops.conv3x3_wgrad(xs, gyn).view(Co, 2, 2, C, 3, 3)   # [co][py][px][ci][ty][tx], tap t = d + 1
     if K == 1:
         return g6[:, 0, 0, :, 1, 1].reshape(Co, C, 1, 1).contiguous()
-    key = str(xn.device)
-    idx = _s2_tap_index.get(key)
-    if idx is None:  # built once per device (outside any graph capture: the first call is a warm-up step)
-        idx = _s2_tap_index[key] = (torch.tensor([1, 0, 1], device=xn.device), torch.tensor([0, 1, 1], device=xn.device))
-    ph, tp = idx
     # advanced indices separated by a slice: the broadcast (ky, kx) dimensions come first
     return g6[:, ph[:, None], ph[None, :], :, tp[:, None], tp[None, :]].permute(2, 3, 0, 1).contiguous()
 
 
+def conv_s2_dgrad_phase_planes(gyn, weight, pad, H, W):
+    """Data gradient of a bias-free stride-2 conv on K8: ONE stride-1 conv over dY (2x2 taps for the 3x3 / 2 conv,
+    4x4 for the 7x7 / 2 stem, 1x1 for the shortcut) that produces the four phase planes of dX, then the depth-to-space
+    copy.  gyn (B,H/2,W/2,Co) bf16 NHWC, weight (Co,C,K,K) fp32 -> dX (B,H,W,C) bf16 NHWC.  Deterministic (the
+    library's transposed-conv kernels are not: the loss of the captured step differed run to run with them)."""
+    B, Ho, Wo, Co = gyn.shape
+    C = weight.shape[1]
+    wp, KT = ops.pack_conv_weight_s2_dgrad(weight.detach().float().contiguous(), pad)
+    ys = ops.conv2d_nhwc(gyn, wp, (KT, KT), 1, KT // 2, tag="conv2d_dgrad")   # (B, Ho + 1, Wo + 1, 4 C) for KT = 2, 4
+    s = 1 if KT > 1 else 0
+    ys = ys[:, s:s + Ho, s:s + Wo].reshape(B, Ho, Wo, 2, 2, C)
+    return ys.permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
+
+
+def _s2_dgrad_native_ok(xn, Co, K):
+    B, H, W, C = xn.shape
+    return (xn.is_cuda and K in (1, 3, 7) and H % 2 == 0 and W % 2 == 0 and Co % 64 == 0 and C % 16 == 0
+            and os.environ.get("LSS_S2_DGRAD_LIB") != "1" and os.environ.get("LSS_S2_DGRAD_GEMM") != "1")
+
+
 def _s2_wgrad_native_ok(xn, Co, K):
     B, H, W, C = xn.shape
-    return (xn.is_cuda and K in (1, 3) and H % 2 == 0 and W % 2 == 0 and (4 * C) % 64 == 0 and Co % 64 == 0
+    return (xn.is_cuda and K in (1, 3, 7) and H % 2 == 0 and W % 2 == 0 and (4 * C) % 64 == 0 and Co % 64 == 0
             and 8 <= W // 2 <= 224 and os.environ.get("LSS_S2_WGRAD_GEMM") != "1")
 
 
 class _ConvS2Fn(torch.autograd.Function):
     """Bias-free stride-2 conv (the 7x7 / 2 stem, the 3x3 / 2 first convs and the 1x1 / 2 shortcuts of layer2 / layer3;
-    ref src/modules.py:99 + torchvision BasicBlock) with the FORWARD on the same K8 phase-plane kernel as inference
-    (bf16 NHWC, fp32 accumulation); the two gradients are im2col + GEMM + col2im on the saved bf16 operands
-    (`conv_s2_backward_gemm`: 5 small layers; graph-safe, which the library's convolution_backward is not)."""
+    ref src/modules.py:99 + torchvision BasicBlock) with all three directions on the HIP kernels over PHASE PLANES
+    (bf16 NHWC, fp32 accumulation): forward = the K8 phase-plane kernel of inference; data gradient = one stride-1 K8
+    conv over dY that yields the four phase planes of dX (`conv_s2_dgrad_phase_planes`); weight gradient = K9w on the
+    phase planes of x (`conv_s2_wgrad_phase_planes`).  The library's `convolution_backward` is kept as an A/B switch
+    only (LSS_S2_DGRAD_LIB=1): its weight-gradient solvers are not safe inside a HIP graph and its data-gradient
+    kernels are not deterministic."""
 
     @staticmethod
     def forward(ctx, x, weight, pad):
@@ -185,7 +214,10 @@ class _ConvS2Fn(torch.autograd.Function):
             else:
                 _, gw = conv_s2_backward_gemm(g.contiguous(), x, weight.detach(), pad, need_x=False)
         if ctx.needs_input_grad[0]:
-            if x.is_cuda and os.environ.get("LSS_S2_DGRAD_GEMM") != "1":
+            if _s2_dgrad_native_ok(xn, weight.shape[0], weight.shape[2]):
+                gx = conv_s2_dgrad_phase_planes(g.permute(0, 2, 3, 1).contiguous(), weight, pad, xn.shape[1],
+                                                xn.shape[2]).permute(0, 3, 1, 2)
+            elif x.is_cuda and os.environ.get("LSS_S2_DGRAD_GEMM") != "1":
                 # data gradient: the library's transposed-conv kernels (no accumulation buffers; replay-checked by
                 # dp.GraphedTrainStep._self_check and tests/test_dp_gpu.py on every replay); 4x cheaper than col2im
                 gx = torch.ops.aten.convolution_backward(

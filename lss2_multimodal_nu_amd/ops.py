@@ -693,6 +693,44 @@ def conv3x3_wgrad(x, dy):
     return dw
 
 
+def pack_conv_weight_s2_dgrad(w_oihw, pad):
+    """OIHW fp32 of a stride-2 K x K conv -> (KT*KT, 4*Cin, Cout) bf16: the weight of the stride-1 conv that maps dY to
+    the four phase planes of dX (lss_conv2d_pack_weights_s2_dgrad).  Returns (packed, KT)."""
+    Cout, Cin, K, _ = w_oihw.shape
+    _f32c(w_oihw, "conv weight")
+    KT = N.lib().lss_conv2d_s2_dgrad_taps(K, pad)
+    if KT == 0:
+        raise ValueError("stride-2 data gradient: K / pad in (1, 0), (3, 1), (7, 3)")
+    out = torch.empty(KT * KT, 4 * Cin, Cout, dtype=torch.bfloat16, device=w_oihw.device)
+    N.check(N.lib().lss_conv2d_pack_weights_s2_dgrad(N.ptr(w_oihw), Cout, Cin, K, pad, N.ptr(out), N.stream()),
+            "lss_conv2d_pack_weights_s2_dgrad")
+    return out, KT
+
+
+def conv4x4_wgrad(xs, dy):
+    """Weight gradient of the 4x4-tap stride-1 conv with taps (dy, dx) in {-2 .. 1}^2 (a 7x7 / 2 / pad-3 conv over
+    phase planes): xs (B,H,W,Cin), dy (B,H,W,Cout) contiguous bf16 NHWC -> (Cout, Cin, 4, 4) fp32, tap [dy + 2][dx + 2]."""
+    B, H, W, Cin = xs.shape
+    Cout = dy.shape[3]
+    for t, nm in ((xs, "xs"), (dy, "dy")):
+        if t.dtype != torch.bfloat16 or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError("%s must be a contiguous bf16 NHWC GPU tensor" % nm)
+    if tuple(dy.shape[:3]) != (B, H, W):
+        raise ValueError("dy %s does not match xs %s" % (tuple(dy.shape), tuple(xs.shape)))
+    nbytes = N.lib().lss_conv2d_wgrad4x4_workspace_bytes(B, H, W, Cin, Cout)
+    if nbytes == 0:
+        raise ValueError("conv4x4_wgrad: channel counts must be multiples of 64 and 8 <= W <= 224")
+    key = ("4x4", B, H, W, Cin, Cout, str(xs.device))
+    ws = _wgrad_ws.get(key)
+    if ws is None:
+        ws = _wgrad_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=xs.device)
+    dw = torch.empty(Cout, Cin, 4, 4, dtype=torch.float32, device=xs.device)
+    with _timed("conv2d_wgrad"):
+        N.check(N.lib().lss_conv2d_wgrad4x4(N.ptr(xs), N.ptr(dy), B, H, W, Cin, Cout, N.ptr(ws), nbytes, N.ptr(dw),
+                                            N.stream()), "lss_conv2d_wgrad4x4")
+    return dw
+
+
 def upsample_cat_nhwc(x, x2, up):
     """[x2 | bilinear_align_corners(x, up)] as a contiguous bf16 (B, H*up, W*up, C2+Cx) tensor."""
     B, H, W, Cx = x.shape

@@ -202,11 +202,13 @@ def test_bn_train_statistics_of_large_mean_channels():
 
 
 @pytest.mark.parametrize("cfg", [(3, 4, 100, 100, 64, 128), (3, 2, 50, 50, 128, 256), (1, 4, 100, 100, 64, 128),
-                                 (1, 2, 50, 50, 128, 256), (3, 1, 36, 44, 64, 64)])
+                                 (1, 2, 50, 50, 128, 256), (3, 1, 36, 44, 64, 64), (7, 4, 200, 200, 64, 64),
+                                 (7, 1, 40, 56, 64, 128)])
 def test_stride2_wgrad_over_phase_planes_vs_torch(cfg):
     """modules.conv_s2_wgrad_phase_planes (K9w on the space-to-depth input + tap / phase selection) against torch's
     weight gradient of the stride-2 conv on the same bf16 operands - the 3x3 / 2 convs and 1x1 / 2 shortcuts of
-    layer2.0 / layer3.0 (torchvision BasicBlock; ref src/modules.py:104-106) - and against the im2col + GEMM form."""
+    layer2.0 / layer3.0 (torchvision BasicBlock; ref src/modules.py:104-106) and the 7x7 / 2 stem (ref :99, the 4x4-tap
+    form: two launches of eight consumer waves) - and against the im2col + GEMM form."""
     from lss2_multimodal_nu_amd import modules as M
     K, B, H, W, C, Co = cfg
     g = torch.Generator().manual_seed(sum(cfg))
@@ -220,3 +222,24 @@ def test_stride2_wgrad_over_phase_planes_vs_torch(cfg):
     _, gw2 = M.conv_s2_backward_gemm(dy.cuda().permute(0, 3, 1, 2), x.cuda().permute(0, 3, 1, 2),
                                      torch.zeros(Co, C, K, K, device="cuda"), K // 2, need_x=False)
     assert float((gw2.cpu() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())   # bf16 products of the batched GEMM
+
+
+@pytest.mark.parametrize("cfg", [(3, 4, 100, 100, 64, 128), (3, 2, 50, 50, 128, 256), (1, 4, 100, 100, 64, 128),
+                                 (1, 2, 50, 50, 128, 256), (7, 4, 200, 200, 64, 64), (7, 1, 40, 56, 64, 128),
+                                 (3, 1, 36, 44, 64, 64)])
+def test_stride2_dgrad_over_phase_planes_vs_torch(cfg):
+    """modules.conv_s2_dgrad_phase_planes (one stride-1 K8 conv over dY that yields the four phase planes of dX + the
+    depth-to-space copy) against torch's input gradient of the stride-2 conv on the same bf16-rounded operands (the
+    7x7 / 2 stem, ref src/modules.py:99; the 3x3 / 2 convs and 1x1 / 2 shortcuts of torchvision's BasicBlock)."""
+    from lss2_multimodal_nu_amd import modules as M
+    K, B, H, W, C, Co = cfg
+    g = torch.Generator().manual_seed(7 + sum(cfg))
+    w = (torch.randn(Co, C, K, K, generator=g) / (K * C ** 0.5)).bfloat16().float()
+    dy = torch.randn(B, H // 2, W // 2, Co, generator=g).bfloat16()
+    ref = torch.nn.grad.conv2d_input((B, C, H, W), w, dy.float().permute(0, 3, 1, 2), stride=2, padding=K // 2)
+    gx = M.conv_s2_dgrad_phase_planes(dy.cuda(), w.cuda(), K // 2, H, W)
+    assert tuple(gx.shape) == (B, H, W, C) and gx.dtype == torch.bfloat16
+    err = float((gx.float().cpu().permute(0, 3, 1, 2) - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 8e-3, err   # one bf16 rounding of the output
+    # deterministic: the same launch twice gives the same bits
+    assert torch.equal(gx, M.conv_s2_dgrad_phase_planes(dy.cuda(), w.cuda(), K // 2, H, W))
