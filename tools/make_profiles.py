@@ -38,7 +38,7 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
     dst = os.path.join(ROOT, "profiles")
     w = lambda name, text: open(os.path.join(dst, "%s_%s" % (rnd, name)), "w").write(text)
-    for tag in ("bench_line", "bench_hires", "bench_fp32", "bench_config1", "bench_train_eager"):
+    for tag in ("bench_line", "bench_hires", "bench_fp32", "bench_config1"):
         p = os.path.join(src, tag + ".json")
         if os.path.exists(p) and os.path.getsize(p):
             w(tag + ".json", json.dumps(last_json_line(p)) + "\n")

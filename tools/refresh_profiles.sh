@@ -12,7 +12,6 @@ ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-train --no-two-streams"  # pr
 cd $R
 python bench.py --steps 100 --warmup 10 > $OUT/bench_line.json 2> $OUT/bench_line.err
 echo "bench line done" 
-LSS_TRAIN_GRAPH=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-two-streams > $OUT/bench_train_eager.json 2>/dev/null
 python bench.py --workload hires --steps 50 --warmup 10 --no-train --no-cpu-baseline > $OUT/bench_hires.json 2>/dev/null
 python bench.py --precision fp32 --steps 20 --warmup 5 --no-train --no-cpu-baseline > $OUT/bench_fp32.json 2>/dev/null
 python bench.py --workload config1 --steps 100 --warmup 10 --no-train > $OUT/bench_config1.json 2>/dev/null
