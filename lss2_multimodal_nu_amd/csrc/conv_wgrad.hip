@@ -301,12 +301,14 @@ namespace {
 
 template <int NTY, int NTX, int DY0, int LP>
 int launch_taps(const WgradPlan& p, WgradArgs& a, hipStream_t st) {
-  static bool attr_set = false;  // per instantiation
-  if (!attr_set) {
+  static bool attr_set[64] = {};  // per instantiation and device (the attribute belongs to the device's code object)
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+  if (dev < 0 || !attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<NTY, NTX, DY0, LP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WK_LDS_MAX);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    if (dev >= 0) attr_set[dev] = true;
   }
   const int grid = (a.Cin / 64) * (a.Cout / 64) * p.nsplit;
   hipLaunchKernelGGL((conv_wgrad_kernel<NTY, NTX, DY0, LP>), dim3(grid), dim3((NTY * NTX + 1 + WK_NXL) * 64), p.lds, st, a);
