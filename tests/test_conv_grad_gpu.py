@@ -243,3 +243,37 @@ def test_stride2_dgrad_over_phase_planes_vs_torch(cfg):
     assert err <= 8e-3, err   # one bf16 rounding of the output
     # deterministic: the same launch twice gives the same bits
     assert torch.equal(gx, M.conv_s2_dgrad_phase_planes(dy.cuda(), w.cuda(), K // 2, H, W))
+
+
+def test_direct_wgrad_odd_geometries():
+    """K9w on shapes chosen to stress its ring protocol rather than its arithmetic: a single image row, fewer rows than row
+    slots, row ranges shorter / longer than the slot ring, widths at both ends of the K-block count, batch 1 and many
+    tiny images, channel tiles in both dimensions - against torch, plus the bounded-wait counter."""
+    shapes = [  # B, H, W, Cin, Cout
+        (1, 1, 33, 64, 64), (1, 2, 8, 64, 128), (7, 3, 9, 128, 64), (1, 64, 224, 64, 64), (2, 37, 65, 192, 64),
+        (5, 5, 160, 64, 192), (1, 129, 31, 128, 128), (16, 4, 40, 64, 64),
+    ]
+    for shape in shapes:
+        B, H, W, Cin, Cout = shape
+        x, dy, _ = _operands(*shape, seed=11 + sum(shape))
+        dw = ops.conv3x3_wgrad(x.cuda(), dy.cuda())
+        ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (Cout, Cin, 3, 3),
+                                          dy.float().permute(0, 3, 1, 2), padding=1)
+        err = float((dw.cpu() - ref).abs().max()) / float(ref.abs().max())
+        assert err <= 2e-4, (shape, err)
+    assert ops.N.lib().lss_conv2d_wgrad_timeouts() == 0
+
+
+def test_wgrad4x4_odd_geometries():
+    """The 16-tap form (two launches of eight consumers, taps {-2 .. 1}^2) on odd geometries, against a dense torch
+    evaluation of the same taps (a 4x4 conv with padding (2, 1) on both axes)."""
+    for B, H, W, Cin, Cout in [(1, 1, 16, 64, 64), (2, 2, 8, 64, 64), (3, 7, 50, 128, 64), (1, 33, 224, 64, 128)]:
+        g = torch.Generator().manual_seed(B + H + W + Cin + Cout)
+        xs = torch.randn(B, H, W, Cin, generator=g).bfloat16()
+        dy = torch.randn(B, H, W, Cout, generator=g).bfloat16()
+        dw = ops.conv4x4_wgrad(xs.cuda(), dy.cuda())          # (Cout, Cin, 4, 4), tap [dy + 2][dx + 2]
+        xp = torch.nn.functional.pad(xs.float().permute(0, 3, 1, 2), (2, 1, 2, 1))     # left 2 / right 1, top 2 / bottom 1
+        ref = torch.nn.grad.conv2d_weight(xp, (Cout, Cin, 4, 4), dy.float().permute(0, 3, 1, 2))
+        err = float((dw.cpu() - ref).abs().max()) / float(ref.abs().max())
+        assert err <= 2e-4, ((B, H, W, Cin, Cout), err)
+    assert ops.N.lib().lss_conv2d_wgrad_timeouts() == 0
