@@ -33,6 +33,10 @@ SHAPES = [
     (3, 54, 67, 64, 128, 0, 2, 0, False),      # 108 x 134 output: ragged columns, odd strip count, no ReLU
     (4, 91, 113, 64, 128, 0, 1, 3, True),      # ragged rows and columns, 3-class head on the plain conv
     (2, 30, 35, 128, 256, 32, 4, 0, True),     # 32-channel skip tensor: one full-resolution chunk + four upsampled
+    (12, 48, 80, 32, 128, 0, 1, 0, True),      # one 32-channel chunk (a single patch buffer generation), many images
+    (1, 200, 200, 64, 128, 0, 1, 0, False),    # batch 1, two chunks, 500 workgroups
+    (10, 13, 27, 96, 128, 0, 4, 0, True),      # 52 x 108 output from a x4 upsample of an odd-sized source, three chunks
+    (10, 7, 100, 64, 128, 0, 2, 2, True),      # 14 x 200: a wide, flat image (rows ragged, columns exact), 2-class head
 ]
 
 
