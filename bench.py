@@ -270,6 +270,7 @@ def main():
         barrier()
         dt_l1 = time.perf_counter() - t1
 
+    guards = {"inference": read_guards()}
     tmax = torch.tensor([dt, dt_l1, dt_cold], dtype=torch.float64, device=dev)
     per_rank = [args.steps * B / dt]
     comm = {"backend": "none", "ranks": 1}
@@ -371,6 +372,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["train"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         wd.cancel()
+        guards["train"] = read_guards()
 
     # ---- informational: two batches in flight (two HIP streams, one model instance each) ------
     # The single-stream number above stays `value`.  This leg shows how much of the step is
@@ -407,15 +409,41 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("config2", "config1"):
         out["cpu_baseline"] = cpu_baseline(model, feats, calib, B)
 
+    # ---- hang guards: every leg's counters in the line; any non-zero one makes the run fail (rc GUARD_RC) ----
+    guards["end"] = read_guards()
+    rc = guards_rc(guards)
+    if dist is not None:
+        worst = torch.tensor([rc], dtype=torch.int32, device=dev)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        rc = int(worst[0])
+    out["guards"] = dict(guards, ok=rc == 0,
+                         note="flag-wait timeout counters of the ring / K9w / chained kernels after each leg (0 = every "
+                              "hand-off completed); non-zero anywhere -> exit code %d" % GUARD_RC)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         wd = _arm_watchdog(60.0, None, rank, "destroy_process_group")  # the line is out; a hung teardown is still rc != 0
         dist.destroy_process_group()
         wd.cancel()
+    if rc:
+        sys.stderr.write("bench.py: loader / consumer flag waits hit their bound: %s\n" % json.dumps(guards))
+        raise SystemExit(rc)
 
 
 WATCHDOG_RC = 3
+GUARD_RC = 4   # a bounded flag wait of a loader / consumer kernel hit its limit during the run: outputs were garbage
+
+
+def read_guards(lib=None):
+    """Timeout counters of the loader / consumer kernels (ops.timeout_counters): read after every leg, OUTSIDE the
+    timed regions (each read synchronises the device)."""
+    from lss2_multimodal_nu_amd import ops
+    return ops.timeout_counters(lib)
+
+
+def guards_rc(guards):
+    """Exit code the counters demand: 0 when every one reads 0."""
+    return GUARD_RC if any(v != 0 for leg in guards.values() for v in leg.values()) else 0
 
 
 def _arm_watchdog(seconds, line, rank, leg="?"):
@@ -447,9 +475,9 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     # N > 1: every p.grad is a view of one flat buffer and the bucket all-reduces start inside backward.
     # N = 1: the reference's loop as it stands (dp.train_step_local) - no flat buffer, no per-parameter `grad += g`
     # One HIP graph per step when this is the only rank (dp.GraphedTrainStep; LSS_TRAIN_GRAPH=0: eager launches); under
-    # data parallelism the bucket all-reduces start from backward hooks and the step stays eager.
+    # data parallelism two graphs around the eager bucket all-reduces (graph A = zero / forward / backward, graph B = clip / Adam).
     graph_env = os.environ.get("LSS_TRAIN_GRAPH", "1") != "0"
-    want_graph = graph_env and world == 1
+    want_graph = graph_env
     bucket = dp.make_bucket(m) if world > 1 else None
     params = bucket.params if bucket is not None else [p for p in m.parameters() if p.requires_grad]
     try:  # the fused single-kernel Adam (same update rule as train.py:42's torch.optim.Adam) where the build has it
@@ -483,17 +511,30 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     def one():  # ref: train.py:49-66 (zero_grad, forward, loss, backward, clip 5.0, Adam) + the DP all-reduce
         dp.train_step(wrapped, bucket, opt, loss_fn, (feats,) + tuple(calib), clip=5.0)
 
-    graph_note = "eager launches (%s)" % ("LSS_TRAIN_GRAPH=0" if not graph_env else "world_size > 1: bucket all-reduces start inside backward")
+    graph_note = "eager launches (LSS_TRAIN_GRAPH=0)"
     if want_graph:
         try:
             graphed = dp.GraphedTrainStep(wrapped, bucket, opt, loss_fn, feats, tuple(calib), clip=5.0, warmup=5)
 
             def one():  # noqa: F811  (the same step, replayed: features and calibration refreshed every step)
                 graphed(feats, tuple(calib))
-            graph_note = "one HIP graph per step (dp.GraphedTrainStep): features + calibration refreshed, then one replay"
+            graph_note = ("one HIP graph per step (dp.GraphedTrainStep): features + calibration refreshed, then one replay"
+                          if graphed.graph_b is None else
+                          "graph under world > 1 (dp.GraphedTrainStep): graph A [zero, forward, backward] -> eager bucket "
+                          "all-reduces -> graph B [clip, Adam]")
         except Exception as e:  # capture refused by a library call: the eager step is still valid
             graph_note = "eager launches (graph capture failed: %s)" % (str(e).splitlines()[0][:160],)
+            graphed = None
             torch.cuda.synchronize()
+        if dist is not None:  # every rank must run the same sequence of collectives: all graphed, or none
+            ok = torch.tensor([0 if graphed is None else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) == 0 and graphed is not None:
+                graphed = None
+                graph_note = "eager launches (graph capture failed on another rank)"
+
+                def one():  # noqa: F811
+                    dp.train_step(wrapped, bucket, opt, loss_fn, (feats,) + tuple(calib), clip=5.0)
     for _ in range(5):  # MIOpen's first-call kernel selection, Adam state, allocator growth: all outside the timed steps
         one()
     if dist is not None:

@@ -220,8 +220,13 @@ __global__ __launch_bounds__((NTY * NTX + 1 + WK_NXL) * 64) void conv_wgrad_kern
   for (int t = 0; t < ntile; ++t) {
     const int pi = pi0 + t;
     const int b = pi / HP, yp = pi - b * HP;
+    // EVERY tile waits for its row slot's fill before releasing it - pad tiles too, although they read nothing: a
+    // release may only ever count for the fill it names.  (Round 3 let pad tiles release without the wait: at an image
+    // boundary inside a row range the fast taps ran through the two pad tiles and released the slot's NEXT fill, and
+    // FREE_X - one summed counter per slot - then reached NCONS x uses while a slow tap was still reading the current
+    // fill: the loader could overwrite a row under a reader (batch >= 2 with nxs <= 5, i.e. W > 128).)
+    rk_wait_ge(flags + F_FULL_X + xslot, WK_NXL * xfill);
     if (yp >= 1 && yp <= a.H) {
-      rk_wait_ge(flags + F_FULL_X + xslot, WK_NXL * xfill);
       const unsigned char* xb = smem + XBASE + xslot * a.xs_bytes;
       for (int j = 0; j < a.KB; ++j) {
         rk_wait_ge(flags + F_FULL_D + dslot, dfill);
@@ -242,7 +247,7 @@ __global__ __launch_bounds__((NTY * NTX + 1 + WK_NXL) * 64) void conv_wgrad_kern
         if (++dslot == WK_NDB) { dslot = 0; ++dfill; }
       }
     }
-    rk_add1(flags + F_FREE_X + xslot, lane);  // (after the tile's last reads, in LDS order; pad tiles release too)
+    rk_add1(flags + F_FREE_X + xslot, lane);  // (after the tile's last reads, in LDS order; pad tiles release too, behind the wait above)
     if (++xslot == a.nxs) { xslot = 0; ++xfill; }
   }
 

@@ -79,6 +79,7 @@ class GradBucket:
         self._fired = set()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._direct = None
+        self.capturing = False  # True while GraphedTrainStep captures backward: the hooks must not start collectives
         self.attach()
 
     # -- the views --------------------------------------------------------------
@@ -118,7 +119,7 @@ class GradBucket:
         self._fired.add(p)
         b = self._bucket_of[p]
         self._ready[b] += 1
-        if self.overlap and self._ready[b] == self.buckets[b][2] and self._world() > 1:
+        if self.overlap and not self.capturing and self._ready[b] == self.buckets[b][2] and self._world() > 1:
             self._launch(b)
             self._ready[b] = -1  # launched
 
@@ -136,6 +137,19 @@ class GradBucket:
                 if self._ready[b] != -1:  # unused parameters in it, or overlap off
                     self._launch(b)
                     self._ready[b] = -1
+            for w in self._work:
+                w.wait()
+            self._work = []
+            self.flat.div_(world)
+
+    def all_reduce_all(self):
+        """The collective of a REPLAYED backward (GraphedTrainStep under data parallelism): no hook ran, so every
+        bucket is launched here, in bucket order, then waited for; grads <- mean over ranks."""
+        world = self._world()
+        if world > 1:
+            self._work = []
+            for b in range(len(self.buckets)):
+                self._launch(b)
             for w in self._work:
                 w.wait()
             self._work = []
@@ -248,12 +262,15 @@ def train_step(model, bucket, opt, loss_fn, inputs, clip=5.0):
     loss = loss_fn(model(*inputs))
     loss.backward()
     bucket.all_reduce_mean()
-    bucket.clip_grad_norm_(clip)
+    _last_norm[0] = bucket.clip_grad_norm_(clip)
     unused = bucket.hide_unused()
     opt.step()
     if unused:
         bucket.attach()
     return loss.detach()
+
+
+_last_norm = [None]  # total gradient 2-norm BEFORE the clip of the latest step (a device tensor: no host sync)
 
 
 def train_step_local(model, opt, loss_fn, inputs, clip=5.0):
@@ -267,16 +284,16 @@ def train_step_local(model, opt, loss_fn, inputs, clip=5.0):
         p.grad = None
     loss = loss_fn(model(*inputs))
     loss.backward()
-    torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], clip, foreach=True)
+    _last_norm[0] = torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], clip, foreach=True)
     opt.step()
     return loss.detach()
 
 
 class GraphedTrainStep:
-    """`train_step` captured once in a HIP graph and replayed: the ~300 launches of a step (19 conv + BatchNorm
-    units forward and backward, the lift-splat pair, loss, clip, Adam) leave the host as ONE launch, so the step
-    runs at the speed of its kernels instead of the speed of the Python / autograd dispatch around them (measured:
-    the eager step is host-bound once the weight-gradient kernels are fast).
+    """`train_step` captured once in HIP graphs and replayed: the ~300 launches of a step (19 conv + BatchNorm
+    units forward and backward, the lift-splat pair, loss, clip, Adam) leave the host as ONE launch (two under data
+    parallelism), so the step runs at the speed of its kernels instead of the speed of the Python / autograd dispatch
+    around them (measured: the eager step is host-bound once the weight-gradient kernels are fast).
 
     Everything a step reads from outside lives in STATIC device buffers that `__call__` refreshes before the
     replay: the feature tensor, the targets the loss function closes over (pass them as `(static_device_tensor,
@@ -284,29 +301,38 @@ class GraphedTrainStep:
     `CalibrationPack` (host inverses as always, data.prepare_calibration; one H2D copy per step).  The optimizer
     must be built with `capturable=True`.
 
-    After capture the step is replayed three times on the capture inputs and the gradients it leaves are checked
-    (`_self_check`): a library kernel that is not safe inside a graph shows up there (MIOpen's weight-gradient
-    solvers were: modules.conv_s2_backward_gemm).
+    One process: ONE graph [zero / drop grads, forward, loss, backward, clip, Adam].
+    Data parallel (`bucket` over a group of more than one rank): graph A = [zero the flat buffer, forward, loss,
+    backward] - the backward hooks count their buckets in but start nothing while capturing -, then the bucket
+    all-reduces EAGERLY on the flat buffer (`GradBucket.all_reduce_all`: the communication library's launches stay
+    outside any capture), then graph B = [clip, Adam] from the same memory pool.  Every rank replays the same sequence,
+    so the collectives match up.
 
-    Single process only.  Under data parallelism the bucket all-reduces are cross-stream launches of the
-    communication library started from backward hooks; a variant with [zero, forward, backward] as a graph and
-    collective + clip + Adam behind it ran clean on one process but left one wild gradient element in a 2-rank gloo
-    run on a shared GPU, could not be tried on RCCL here, and is not shipped: `train_step` stays eager there."""
+    After capture the step is replayed three times on the capture inputs and checked (`_self_check`): the total
+    gradient norm BEFORE the clip (the clip would hide any finite garbage: it rescales whatever it is handed to the
+    clip value) must be finite, positive and stable, and the loader / consumer kernels' timeout counters must read 0
+    (`ops.assert_no_timeouts`).  A library kernel that is not safe inside a graph shows up there (MIOpen's
+    weight-gradient solvers were: modules.conv_s2_backward_gemm)."""
 
     CHECK_REPLAYS = 3  # replays of the self-check after capture (ordinary steps on the capture inputs)
 
     def __init__(self, model, bucket, opt, loss_fn, feats, calib, clip=5.0, warmup=3):
+        from . import modules
         from .data import CalibrationPack, prepare_calibration
+        if warmup < 1:
+            raise ValueError("GraphedTrainStep needs at least one eager warm-up step before the capture (first-call "
+                             "work - kernel attributes, index tables, optimizer state - must not happen inside it)")
         if not feats.is_cuda:
             raise ValueError("GraphedTrainStep: features must be on the GPU")
-        if bucket is not None and bucket._world() > 1:
-            raise RuntimeError("GraphedTrainStep is single-process; use train_step under data parallelism")
+        modules.warm_s2_tables(feats.device)  # (pageable H2D copies: refused inside a capture)
         self._prepare = prepare_calibration
         self.feats = feats.detach().clone()
         host = calib if isinstance(calib, CalibrationPack) else prepare_calibration(*calib)
         self.pack = CalibrationPack(host.buffer.to(feats.device), host.shape)
         self._inputs = (self.feats, self.pack, None, None, None, None)
         self._params = [p for g in opt.param_groups for p in g["params"]]
+        self.bucket = bucket
+        self.distributed = bucket is not None and bucket._world() > 1
 
         def step():
             return train_step(model, bucket, opt, loss_fn, self._inputs, clip=clip)
@@ -320,29 +346,56 @@ class GraphedTrainStep:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = step()
+        self.graph_b = None
+        if not self.distributed:
+            with torch.cuda.graph(self.graph):
+                self.loss = step()
+            self.grad_norm = _last_norm[0]
+        else:
+            bucket.capturing = True
+            try:
+                # (thread-local capture mode: the process group's watchdog thread keeps querying its events meanwhile)
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    bucket.zero()
+                    loss = loss_fn(model(*self._inputs))
+                    loss.backward()
+                    self.loss = loss.detach()
+            finally:
+                bucket.capturing = False
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                self.grad_norm = bucket.clip_grad_norm_(clip)
+                unused = bucket.hide_unused()
+                opt.step()
+                if unused:
+                    bucket.attach()
         self._self_check()
 
-    def _grad_norm(self):
-        gs = [p.grad for p in self._params if p.grad is not None]
-        return float(torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g.float()) for g in gs])))
+    def _replay(self):
+        self.graph.replay()
+        if self.graph_b is not None:
+            self.bucket.all_reduce_all()
+            self.graph_b.replay()
 
     def _self_check(self):
-        """Replay the captured step three times on the inputs it was captured with and look at the (clipped)
-        gradients it leaves: a kernel that accumulates into a buffer which is only cleared outside the captured
-        stream shows up as gradients that explode, vanish or go non-finite from the second replay on - seen with
-        MIOpen's weight-gradient solvers: 1e30 in one tensor, which the clip then turned into an all-zero gradient
-        while Adam's momentum kept the loss moving.  (The replays are ordinary training steps: extra warm-up.)"""
+        """Replay the captured step on the inputs it was captured with and look at what it leaves: the PRE-clip total
+        gradient norm (a static tensor of the captured step) and the loader / consumer kernels' timeout counters.  A
+        kernel that accumulates into a buffer which is only cleared outside the captured stream shows up as a norm
+        that explodes, vanishes or goes non-finite from the second replay on - seen with MIOpen's weight-gradient
+        solvers: 1e30 in one tensor, which the clip then turned into an all-zero gradient while Adam's momentum kept
+        the loss moving.  (Round 3 looked at the gradients AFTER the clip: any finite garbage above the clip value
+        came out as norm ~ clip and passed - ADVICE r3.)  The replays are ordinary training steps: extra warm-up."""
+        from . import ops
         norms = []
         for _ in range(self.CHECK_REPLAYS):
-            self.graph.replay()
+            self._replay()
             torch.cuda.synchronize()
-            norms.append(self._grad_norm())
+            norms.append(float(self.grad_norm))
         ok = all(n == n and 0.0 < n < float("inf") for n in norms) and max(norms) <= 20.0 * min(norms)
         if not ok:
-            raise RuntimeError("replayed gradients are not stable (norms %s): something in the step is not graph-safe"
-                               % (", ".join("%.3g" % n for n in norms),))
+            raise RuntimeError("replayed gradients are not stable (pre-clip norms %s): something in the step is not "
+                               "graph-safe" % (", ".join("%.3g" % n for n in norms),))
+        ops.assert_no_timeouts("GraphedTrainStep self-check")
 
     def __call__(self, feats, calib, refresh=()):
         """One step on new inputs; returns the (static) loss tensor.  `refresh`: (static_tensor, new_value) pairs
@@ -356,5 +409,5 @@ class GraphedTrainStep:
                 self.pack.buffer.copy_(host.buffer, non_blocking=True)
         for dst, src in refresh:
             dst.copy_(src, non_blocking=True)
-        self.graph.replay()
+        self._replay()
         return self.loss

@@ -72,8 +72,9 @@ class _LiftSplatFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, calib, consts, ws, dims, nx, math, layout):
         inv_pr, comb, ptr, trn = calib
         frustum, dx, bx = consts
-        bev, depth, feat = ops.lift_splat_forward(frustum, inv_pr, ptr, comb, trn, dx, bx, x.contiguous(), weight, bias,
-                                                  ws, dims, nx, layout, math)
+        with _histogram_guard(ws):  # a failed call must not leave the zero-between-calls words of the workspace dirty
+            bev, depth, feat = ops.lift_splat_forward(frustum, inv_pr, ptr, comb, trn, dx, bx, x.contiguous(), weight,
+                                                      bias, ws, dims, nx, layout, math)
         ctx.save_for_backward(x, weight, depth, feat, ws.voxel.clone())
         ctx.dims, ctx.nx = dims, nx
         return bev
@@ -324,13 +325,13 @@ class _LiftSplatMixin:
         host = self._host_calib(rots, trans, intrins, post_rots, post_trans, BN) if ce.math == "fp32" else None
         if host is not None:
             # host calibration rides in the kernel arguments: no H2D copy, no staging buffer
-            with ops.region("lift_splat_level"):
+            with ops.region("lift_splat_level"), _histogram_guard(ws):
                 bev, _, _ = ops.lift_splat_forward_hostcal(self.frustum.detach(), host, self.dx.detach(), self.bx.detach(),
                                                            x.float().contiguous(), ce.depthnet.weight.detach(),
                                                            ce.depthnet.bias.detach(), ws, dims, nx, layout)
             return bev
         inv_pr, comb, ptr, trn = self._device_calib(dev, rots, trans, intrins, post_rots, post_trans)
-        with ops.region("lift_splat_level"):
+        with ops.region("lift_splat_level"), _histogram_guard(ws):
             bev, _, _ = ops.lift_splat_forward(self.frustum.detach(), inv_pr, ptr, comb, trn, self.dx.detach(),
                                                self.bx.detach(), x.float().contiguous(), ce.depthnet.weight.detach(),
                                                ce.depthnet.bias.detach(), ws, dims, nx, layout, _PRECISIONS[ce.math])

@@ -121,6 +121,28 @@ def conv_s2_backward_gemm(g, x, weight, pad, need_x=True, need_w=True):
 _s2_tap_index = {}
 
 
+def _s2_tables(device, K):
+    """(phase, tap) index tensors of a K x K / stride-2 kernel on `device`: kernel row k reads input row
+    2 oy + k - K // 2 = 2 (oy + d) + p, i.e. phase p and tap index t = d - d_min.  Building them is a pageable
+    host-to-device copy, which a stream capture refuses: `warm_s2_tables` builds them ahead of any capture
+    (dp.GraphedTrainStep calls it; BevEncode does when it is moved to a device)."""
+    key = (str(device), K)
+    idx = _s2_tap_index.get(key)
+    if idx is None:
+        if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("stride-2 tap tables for %s are not built yet and a stream capture is active: call "
+                               "modules.warm_s2_tables(device) before capturing" % (device,))
+        ds = [(k - K // 2) // 2 for k in range(K)]
+        idx = _s2_tap_index[key] = (torch.tensor([(k - K // 2) % 2 for k in range(K)], device=device),
+                                    torch.tensor([d - min(ds) for d in ds], device=device))
+    return idx
+
+
+def warm_s2_tables(device):
+    for K in (1, 3, 7):
+        _s2_tables(device, K)
+
+
 def conv_s2_wgrad_phase_planes(xn, gyn, K):
     """Weight gradient of a bias-free stride-2 conv with K in {1, 3, 7} (pad K // 2) on K9w (csrc/conv_wgrad.hip): in
     phase planes xs[b, y, x, (py, px, c)] = x[b, 2y + py, 2x + px, c] the conv is a stride-1 conv with taps
@@ -131,14 +153,7 @@ def conv_s2_wgrad_phase_planes(xn, gyn, K):
     B, H, W, C = xn.shape
     Co = gyn.shape[3]
     xs = xn.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // 2, W // 2, 4 * C)
-    key = (str(xn.device), K)
-    idx = _s2_tap_index.get(key)
-    if idx is None:  # built once per device (outside any graph capture: the first call is a warm-up step)
-        # kernel row k reads input row 2 oy + k - K // 2 = 2 (oy + d) + p: phase p and tap index t = d - d_min
-        ds = [(k - K // 2) // 2 for k in range(K)]
-        idx = _s2_tap_index[key] = (torch.tensor([(k - K // 2) % 2 for k in range(K)], device=xn.device),
-                                    torch.tensor([d - min(ds) for d in ds], device=xn.device))
-    ph, tp = idx
+    ph, tp = _s2_tables(xn.device, K)
     if K == 7:  # the stem: taps d in {-2 .. 1} -> the 4x4-tap form of K9w (two launches of eight consumer waves)
         g6 = ops.conv4x4_wgrad(xs, gyn).view(Co, 2, 2, C, 4, 4)
         return g6[:, ph[:, None], ph[None, :], :, tp[:, None], tp[None, :]].permute(2, 3, 0, 1).contiguous()
@@ -408,14 +423,21 @@ def enable_sync_bn(module, group=None):
     return module
 
 
-_batch_counters = [None]  # a list while BevEncode.features collects its BatchNorms' counters, else None
+def x_is_capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+import threading  # noqa: E402
+
+_tls = threading.local()  # .counters: a list while BevEncode.features (of THIS thread) collects its BatchNorms' counters
 
 
 def _count_batch(bn):
     """`num_batches_tracked += 1` of a BatchNorm that ran on a native unit (torch's own forward does it itself).
     Inside BevEncode.features the 18 counters are bumped by ONE foreach launch at the end instead of 18 kernels."""
-    if _batch_counters[0] is not None:
-        _batch_counters[0].append(bn.num_batches_tracked)
+    pending = getattr(_tls, "counters", None)
+    if pending is not None:
+        pending.append(bn.num_batches_tracked)
     else:
         bn.num_batches_tracked.add_(1)
 
@@ -835,7 +857,7 @@ class BevEncode(nn.Module):
         x = x.float() if x.dtype != torch.float32 else x
         if _native_training() and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)  # the whole chain then stays NHWC
-        outer, _batch_counters[0] = _batch_counters[0], []
+        outer, _tls.counters = getattr(_tls, "counters", None), []
         try:
             x = _train_bn_act(self.bn1, _train_conv(self.conv1, x), relu=True)
             x1 = self.layer1(x)
@@ -844,7 +866,7 @@ class BevEncode(nn.Module):
             u = self.up2
             return _train_conv_bn_act(u[1], u[2], x, relu=True, up=u[0])
         finally:
-            counters, _batch_counters[0] = _batch_counters[0], outer
+            counters, _tls.counters = _tls.counters, outer
             if counters:
                 torch._foreach_add_(counters, 1)
 
@@ -862,7 +884,11 @@ class BevEncode(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self.invalidate_plan()
-        return super()._apply(fn, *a, **k)
+        out = super()._apply(fn, *a, **k)
+        dev = self.conv1.weight.device
+        if dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            warm_s2_tables(dev)  # index tensors of the stride-2 weight gradients: never built inside a capture
+        return out
 
     def load_state_dict(self, *a, **k):
         self.invalidate_plan()
@@ -908,11 +934,26 @@ class BevEncode(nn.Module):
                 finally:
                     ops.set_recorder(None)
                 self._plans[key] = (ops.ConvPlan(rec, x, out), self._plan_stamp())
+                self._guard("BevEncode (launch plan recorded)")
                 return out.clone()  # the recorded output buffer stays with the plan
             out = torch.empty(x.shape[0], self.up2[4].out_channels, x.shape[1], x.shape[2],
                               dtype=torch.float32, device=x.device)
             ent[0].run(x, out)
+            every = ops.guard_every()
+            if every:
+                n = self.__dict__["_guard_calls"] = self.__dict__.get("_guard_calls", 0) + 1
+                if n % every == 0:
+                    self._guard("BevEncode (call %d)" % n)
             return out
+
+    @staticmethod
+    def _guard(where):
+        """The ring kernels' flag waits are bounded; a hit leaves garbage in the output (ops.assert_no_timeouts).
+        Checked whenever a plan is (re-)recorded and every LSS_GUARD_EVERY-th replay; a device synchronisation each
+        time, so never inside a stream capture."""
+        if x_is_capturing():
+            return
+        ops.assert_no_timeouts(where)
 
     def _forward_nhwc(self, x, dt):
         x = self._stem.run(x, dt, relu=True)

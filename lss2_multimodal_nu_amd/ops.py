@@ -74,6 +74,38 @@ def region(tag):
     return _timed(tag, coarse=True)
 
 
+# --- hang guards of the loader / consumer kernels (conv_ring.hip, conv_wgrad.hip, chained convs) ---------------------
+# Every FULL / FREE flag wait of those kernels is bounded; a wait that hits its bound ends the grid instead of hanging
+# the GPU, bumps a device counter and leaves GARBAGE in that launch's output.  The counters are therefore part of the
+# product's contract, not a test detail: bench.py reads them after every leg, BevEncode whenever it records a launch
+# plan (and every LSS_GUARD_EVERY-th call), dp.GraphedTrainStep in its self-check.
+GUARD_COUNTERS = ("lss_conv2d_ring_timeouts", "lss_conv2d_wgrad_timeouts")
+
+
+def timeout_counters(lib=None):
+    """{counter name: value} of the flag-wait timeout counters (0 = every hand-off completed; -1 = the counter could
+    not be read).  Synchronises the device (a device-to-host copy of one int each): never call inside a stream capture."""
+    L = lib if lib is not None else N.lib()
+    return {name[len("lss_conv2d_"):]: int(getattr(L, name)()) for name in GUARD_COUNTERS}
+
+
+def assert_no_timeouts(where, lib=None):
+    """Raise LssNativeError when a loader / consumer hand-off of any launch so far ran into its bound."""
+    bad = {k: v for k, v in timeout_counters(lib).items() if v != 0}
+    if bad:
+        raise N.LssNativeError("%s: flag waits of the loader / consumer kernels hit their bound (%s): the affected "
+                               "launches produced garbage" % (where, ", ".join("%s=%d" % kv for kv in sorted(bad.items()))))
+
+
+def guard_every():
+    """LSS_GUARD_EVERY=N: BevEncode checks the counters on every N-th inference call (0 / unset: only when it records a
+    launch plan; each check is a device synchronisation)."""
+    try:
+        return max(0, int(os.environ.get("LSS_GUARD_EVERY", "0")))
+    except ValueError:
+        return 0
+
+
 class ConvRecorder:
     """Collects the conv launches of one eager pass (pointers + shapes) together with the
     tensors that must outlive them; `ConvPlan` replays the list with ONE native call."""

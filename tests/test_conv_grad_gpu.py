@@ -46,6 +46,37 @@ def test_conv3x3_wgrad_vs_torch(shape):
     assert ops.N.lib().lss_conv2d_wgrad_timeouts() == 0, "a flag wait of the direct wgrad kernel hit its bound"
 
 
+# Image boundaries INSIDE a row range at widths whose X ring is short (W > 128: five row slots at 160, four at 200 /
+# 224): the case in which round 3's pad tiles released a row slot without waiting for its fill and the loader could
+# lap a slow tap.  Few, long row ranges (LSS_WGRAD_SPLITS) put every interior boundary inside a range.
+BOUNDARY_SHAPES = [  # B, H, W, Cin, Cout, splits
+    (4, 200, 200, 64, 64, None),   # the benched up2-like geometry at batch 4 (layer width 200, four row slots)
+    (6, 9, 200, 64, 64, 1),        # five interior boundaries in ONE range
+    (5, 7, 224, 64, 128, 2),       # the widest rows, two ranges
+    (4, 11, 160, 128, 64, 1),      # five row slots
+    (3, 6, 136, 64, 64, 1),        # five K blocks, the last one 8 positions
+]
+
+
+@pytest.mark.parametrize("shape", BOUNDARY_SHAPES)
+def test_conv3x3_wgrad_image_boundaries_inside_a_row_range(shape, monkeypatch):
+    B, H, W, Cin, Cout, splits = shape
+    if splits is not None:
+        monkeypatch.setenv("LSS_WGRAD_SPLITS", str(splits))
+    ops._wgrad_ws.clear()
+    x, dy, _ = _operands(B, H, W, Cin, Cout, seed=B + H + W)
+    xg, dyg = x.cuda(), dy.cuda()
+    dw = ops.conv3x3_wgrad(xg, dyg)
+    ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (Cout, Cin, 3, 3),
+                                      dy.float().permute(0, 3, 1, 2), padding=1)
+    err = float((dw.cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-4, err
+    for _ in range(5):  # a lapped row slot is timing-dependent: the result must not move
+        assert torch.equal(dw, ops.conv3x3_wgrad(xg, dyg))
+    assert ops.N.lib().lss_conv2d_wgrad_timeouts() == 0
+    ops._wgrad_ws.clear()
+
+
 def test_conv3x3_wgrad_gemm_path_still_agrees(monkeypatch):
     """LSS_WGRAD_DIRECT=0: the channel-major copies + split-K GEMM (the only path for widths outside 8..224 or
     channel counts that are not multiples of 64) against the direct kernel on a shape both take."""

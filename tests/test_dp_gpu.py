@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, graphed=False, batch=1):
     import torch.distributed as dist
 
     import lss2_multimodal_nu_amd as L
@@ -34,14 +34,14 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     torch.manual_seed(0)
-    m = L.compile_model_lss(1, GRID, AUG, 4).cuda().train()  # one sample per rank
+    m = L.compile_model_lss(batch, GRID, AUG, 4).cuda().train()  # `batch` samples per rank
     bucket = dp.GradBucket(m.parameters())
-    opt = torch.optim.Adam(bucket.params, lr=1e-3)
+    opt = torch.optim.Adam(bucket.params, lr=1e-3, capturable=graphed)
     g = torch.Generator().manual_seed(100 + rank)  # different data per rank
-    x = torch.randn(6, 512, 8, 22, generator=g).cuda()
-    tgt = torch.randint(0, 4, (1, 200, 200), generator=g).cuda()
+    x = torch.randn(6 * batch, 512, 8, 22, generator=g).cuda()
+    tgt = torch.randint(0, 4, (batch, 200, 200), generator=g).cuda()
     w = torch.tensor([1.0, 10.0, 5.0, 10.0]).cuda()
-    calib = lo.synthetic_rig(1, 6, train_aug=True, seed=rank)
+    calib = lo.synthetic_rig(batch, 6, train_aug=True, seed=rank)
 
     class Amp(torch.nn.Module):
         def __init__(self, inner):
@@ -57,15 +57,41 @@ def _worker(rank, world, port, out):
     ops.set_timer(spans)
     losses = []
     loss_fn = lambda y: weighted_cross_entropy(y.float(), tgt, w)  # noqa: E731
-    for _ in range(4):
-        losses.append(float(dp.train_step(wrapped, bucket, opt, loss_fn, (x,) + tuple(calib))))
+    launch = "eager"
+    if graphed:
+        ops.set_timer(None)  # (HIP-event brackets do not belong inside a capture)
+        gs = dp.GraphedTrainStep(wrapped, bucket, opt, loss_fn, x, tuple(calib), warmup=2)
+        launch = "graph A + eager all-reduce + graph B" if gs.graph_b is not None else "one graph"
+        for _ in range(6):
+            losses.append(float(gs(x, tuple(calib))))
+    else:
+        for _ in range(4):
+            losses.append(float(dp.train_step(wrapped, bucket, opt, loss_fn, (x,) + tuple(calib))))
     ops.set_timer(None)
+    torch.cuda.synchronize()
+    counters = ops.timeout_counters()
     flat = torch.cat([p.detach().reshape(-1) for p in bucket.params]).cpu()
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
+    every = [None] * world
+    dist.all_gather_object(every, counters)
     if rank == 0:
+        # where the ranks part, if they do: first differing element -> parameter name (the flat order is bucket.params')
+        where = None
+        for t in gathered[1:]:
+            bad = (gathered[0] != t).nonzero()
+            if bad.numel():
+                i, o = int(bad[0]), 0
+                for (n, p) in m.named_parameters():
+                    if p.requires_grad:
+                        if o <= i < o + p.numel():
+                            where = (n, i - o, float(gathered[0][i]), float(t[i]), int(bad.numel()))
+                            break
+                        o += p.numel()
+                break
         torch.save({"equal": all(torch.equal(gathered[0], t) for t in gathered), "losses": losses,
-                    "tags": sorted(spans.spans), "finite": bool(torch.isfinite(flat).all())}, out)
+                    "tags": sorted(spans.spans), "finite": bool(torch.isfinite(flat).all()), "where": where,
+                    "counters": every, "launch": launch}, out)
     dist.destroy_process_group()
 
 
@@ -78,6 +104,25 @@ def test_two_rank_gpu_training_keeps_ranks_identical(tmp_path):
     assert got["equal"] and got["finite"]
     assert {"conv_bn_act_train_fwd", "conv_bn_act_train_bwd", "weighted_ce_fwd"} <= set(got["tags"])
     assert got["losses"][-1] < got["losses"][0]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("batch", [1, 2])
+def test_two_rank_graphed_training_keeps_ranks_identical(tmp_path, batch):
+    """dp.GraphedTrainStep under data parallelism: [zero, forward, backward] and [clip, Adam] as two HIP graphs around
+    the eager all-reduce of the flat gradient buffer; two ranks on the one GPU of the box (gloo), different data per
+    rank - identical parameters on both after every step, finite, loss going down, no flag wait of a loader / consumer
+    kernel at its bound.  (Round 3's first version of this form left one wild gradient element in this very test and
+    was withdrawn; on a mismatch the message names the parameter and the element where the ranks part.)  batch 2 per
+    rank puts an image boundary inside the weight-gradient kernel's row ranges (the K9w row-slot case of ADVICE r3)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "dp_gpu_graph.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out, True, batch), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["launch"].startswith("graph A"), got["launch"]
+    assert all(v == 0 for c in got["counters"] for v in c.values()), got["counters"]
+    assert got["equal"] and got["finite"], (got["where"], got["losses"])
+    assert got["losses"][-1] < got["losses"][0], got["losses"]
 
 
 def _sync_worker(rank, world, port, out):

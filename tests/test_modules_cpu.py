@@ -247,14 +247,20 @@ def test_batch_counters_are_collected_and_flushed_once():
     bns = [torch.nn.BatchNorm2d(8) for _ in range(3)]
     M._count_batch(bns[0])
     assert int(bns[0].num_batches_tracked) == 1
-    outer, M._batch_counters[0] = M._batch_counters[0], []
+    outer, M._tls.counters = getattr(M._tls, "counters", None), []
     try:
         for bn in bns:
             M._count_batch(bn)
         assert [int(b.num_batches_tracked) for b in bns] == [1, 0, 0]   # nothing bumped yet
-        torch._foreach_add_(M._batch_counters[0], 1)
+        # the collector belongs to THIS thread: another thread's BatchNorm is bumped at once
+        import threading
+        other = torch.nn.BatchNorm2d(8)
+        th = threading.Thread(target=M._count_batch, args=(other,))
+        th.start(); th.join()
+        assert int(other.num_batches_tracked) == 1 and len(M._tls.counters) == 3
+        torch._foreach_add_(M._tls.counters, 1)
     finally:
-        M._batch_counters[0] = outer
+        M._tls.counters = outer
     assert [int(b.num_batches_tracked) for b in bns] == [2, 1, 1]
     be = M.BevEncode(64, 4)
     be.train()
@@ -262,7 +268,7 @@ def test_batch_counters_are_collected_and_flushed_once():
         be.features(torch.zeros(1, 3, 8, 8))   # wrong channel count: raises inside the collecting region
     except Exception:
         pass
-    assert M._batch_counters[0] is None
+    assert getattr(M._tls, "counters", None) is None
 
 
 def test_conv_s2_backward_gemm_equals_autograd():
