@@ -564,6 +564,18 @@ int lss_head_ce_bwd(const void* y, const float* head_w, const float* head_b, con
                     const float* class_w, long long M, int Cin, int K, const float* sums, const float* grad_loss,
                     float* workspace, void* dy, float* d_head_w, float* d_head_b, void* stream);
 
+/* The 1x1 head ALONE, forward and backward, for a training-mode `model(x)` whose loss the caller computes
+ * (ref src/modules.py:115 `up2[4] = nn.Conv2d(128, outC, kernel_size=1)` and its autograd behind train.py:61 when the
+ * loss is `MultiLoss` over returned logits, src/tools.py:232-251).  y: (M, 128) bf16 NHWC rows, M = B * HW;
+ * logits / grad_logits: (B, K, H, W) fp32 NCHW; K in {4, 8}.  The backward leaves dy (M, 128) bf16 and the
+ * fixed-order sums d_head_w (K, 128), d_head_b (K); workspace: lss_head_ce_workspace_bytes(K).  Exists because the
+ * library convolution's backward is not replay-safe inside a HIP graph. */
+int lss_head1x1_fwd(const void* y, const float* head_w, const float* head_b, long long M, long long HW, int Cin, int K,
+                    float* logits, void* stream);
+int lss_head1x1_bwd(const void* y, const float* head_w, const float* head_b, const float* grad_logits, long long M,
+                    long long HW, int Cin, int K, float* workspace, void* dy, float* d_head_w, float* d_head_b,
+                    void* stream);
+
 /* ---- data-parallel gradient step (the reference has no collective on this path: its loop is
  * `loss.backward(); clip_grad_norm_(5.0); opt.step()`, train.py:63-65, on one device) --------------------------
  * One process per GPU; the flat fp32 gradient buffer (every p.grad is a view of it) is summed in place over

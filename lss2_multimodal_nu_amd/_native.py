@@ -84,6 +84,8 @@ SIGNATURES = {
     "lss_head_ce_workspace_bytes": (_sz, [_i]),
     "lss_head_ce_fwd": (_i, [_vp] * 5 + [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp]),
     "lss_head_ce_bwd": (_i, [_vp] * 5 + [ctypes.c_longlong, _i, _i] + [_vp] * 7),
+    "lss_head1x1_fwd": (_i, [_vp] * 3 + [ctypes.c_longlong, ctypes.c_longlong, _i, _i, _vp, _vp]),
+    "lss_head1x1_bwd": (_i, [_vp] * 4 + [ctypes.c_longlong, ctypes.c_longlong, _i, _i] + [_vp] * 5),
     "lss_rccl_unique_id_bytes": (_sz, []),
     "lss_rccl_version": (_i, [_vp]),
     "lss_rccl_get_unique_id": (_i, [_vp]),

@@ -660,6 +660,43 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
     esh[ct] = (cok && a.shift) ? a.shift[co] : 0.f;
   }
 
+  // Output pieces of this thread (used by the epilogue; computed here because the residual rows of the launch-bound
+  // layers are requested from inside the main loop, see EARLY_RES).  A piece = 8 consecutive channels (16 B of bf16) of
+  // one pixel; 256 threads cover PPJ pixels x CG channel groups per pass, so a thread's pixel column, channel group and
+  // first row never change: every per-pass address is one base + a compile-time offset.
+  constexpr int CG = BN / 8;              // 16-B channel groups per pixel
+  constexpr int PPJ = 256 / CG;           // pixels per pass
+  constexpr int RPJ = PPJ / 16;           // image rows per pass
+  constexpr int HROWS = TH / EPH;         // image rows per staged half (EPH = 2: KC = 32, see OUT_BYTES)
+  constexpr int HPIECES = HROWS * 16 * CG;
+  constexpr int EPJ = HPIECES / 256;      // passes per half
+  static_assert(HPIECES % 256 == 0 && PPJ % 16 == 0, "half tiles split evenly over the threads");
+  const int pix0 = tid / CG, c8 = tid % CG;
+  const int ox = ox0 + (pix0 & 15), oyb = oy0 + (pix0 >> 4);
+  const int co = n0 + c8 * 8;
+  const bool col_ok = grp == 0 && ox < a.Wo && co < a.Cout;
+  const size_t pixb = ((size_t)b * a.Ho + oyb) * a.Wo + ox;  // pixel index of pass 0 of half 0
+  const int rstep = a.Wo * a.Cout;                            // residual elements per image row
+  const unsigned short* res = reinterpret_cast<const unsigned short*>(a.residual);
+  const bool res_vec = !HEAD && res != nullptr && col_ok && (a.Cout & 7) == 0 && co + 8 <= a.Cout;
+  // EARLY_RES: the residual rows of the launch-bound layers (RT = 1: 152-190 registers, room for 16 more) are
+  // requested at the top of the LAST chunk's taps instead of at the top of the epilogue: phase stamps put the store
+  // phase of the residual layers at 1.6-1.7 us against 1.0-1.1 us for the same tile without a residual - the loads,
+  // issued ~0.6 us before their first use, were still in flight when the store loop wanted them.
+  constexpr bool EARLY_RES = RT == 1 && EPH == 1 && !HEAD;
+  uint4 rres[HEAD ? 1 : EPJ];
+  auto load_residual = [&](int half) {
+    if (!HEAD) {
+      const unsigned short* rb = res + pixb * a.Cout + co;
+#pragma unroll
+      for (int j = 0; j < EPJ; ++j) {
+        const int row = half * HROWS + j * RPJ;
+        rres[j] = make_uint4(0, 0, 0, 0);
+        if (res_vec && oyb + row < a.Ho) rres[j] = *reinterpret_cast<const uint4*>(rb + row * rstep);
+      }
+    }
+  };
+
   // prologue: W(0), W(1) on their way; patch of chunk 0
   if (src_chunk(0)) issue_src(0);
   issue_w(0, 0);
@@ -698,6 +735,7 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const bool last_chunk = chunk + 1 == nchunks;
     const bool srcq = src_chunk(chunk + 1);  // this chunk's tap 0 also sends the next chunk's source pixels
+    if (EARLY_RES && last_chunk) load_residual(0);  // (younger than every DMA piece the counted waits below name)
     read_a(0, 0, 0);
     read_b(0, slot, 0);
 #pragma unroll
@@ -790,35 +828,18 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
     }
     lds_barrier();  // the partials are consumed before group 0 restages the tile below
   }
-  // Output pieces of this thread.  A piece = 8 consecutive channels (16 B of bf16) of one pixel;
-  // 256 threads cover PPJ pixels x CG channel groups per pass, so a thread's pixel column, channel
-  // group and first row never change: every per-pass address is one base + a compile-time offset
-  // (the epilogue of the launch-bound layers is instruction-issue time, not bandwidth).
-  constexpr int CG = BN / 8;              // 16-B channel groups per pixel
-  constexpr int PPJ = 256 / CG;           // pixels per pass
-  constexpr int RPJ = PPJ / 16;           // image rows per pass
-  constexpr int HROWS = TH / EPH;         // image rows per staged half (EPH = 2: KC = 32, see OUT_BYTES)
-  constexpr int HPIECES = HROWS * 16 * CG;
-  constexpr int EPJ = HPIECES / 256;      // passes per half
-  static_assert(HPIECES % 256 == 0 && PPJ % 16 == 0, "half tiles split evenly over the threads");
-  const int pix0 = tid / CG, c8 = tid % CG;
-  const int ox = ox0 + (pix0 & 15), oyb = oy0 + (pix0 >> 4);
-  const int co = n0 + c8 * 8;
+  // (the epilogue of the launch-bound layers is instruction-issue time, not bandwidth)
   // dual-output launches: this workgroup's channel block belongs to y (columns [0, split)) or y2
   const bool second = a.y2 != nullptr && n0 >= a.split;
   const int ycol0 = second ? a.split : 0;                                   // first channel of the tensor
   const int ycw = a.y2 == nullptr ? a.Cout : (second ? a.Cout - a.split : a.split);  // its channel count
   const int eact = n0 < a.relu_n ? a.relu : 0;
   const bool vec_ok = (ycw & 7) == 0 && co + 8 <= a.Cout;  // 16-B aligned, whole channel group
-  const bool col_ok = grp == 0 && ox < a.Wo && co < a.Cout;
-  const size_t pixb = ((size_t)b * a.Ho + oyb) * a.Wo + ox;  // pixel index of pass 0 of half 0
-  const int ystep = a.Wo * ycw, rstep = a.Wo * a.Cout;       // elements per image row
+  const int ystep = a.Wo * ycw;                               // output elements per image row
   // residual rows of ONE staged half: requested at the top of the half's iteration, before its accumulators are
   // staged, so the loads fly during the LDS write / barrier / read-back instead of stalling the store loop.  (Per
-  // half, not for the whole tile: 16 instead of 32 live registers in the 168-register KC = 32 kernels.)
-  uint4 rres[HEAD ? 1 : EPJ];
-  const unsigned short* res = reinterpret_cast<const unsigned short*>(a.residual);
-  const bool res_vec = !HEAD && res != nullptr && col_ok && (a.Cout & 7) == 0 && co + 8 <= a.Cout;
+  // half, not for the whole tile: 16 instead of 32 live registers in the 168-register KC = 32 kernels.)  The RT = 1
+  // kernels have requested them inside the main loop already (EARLY_RES).
   unsigned short* y = reinterpret_cast<unsigned short*>(second ? a.y2 : a.y);
   const size_t obase = pixb * ycw + (co - ycol0);
   const __amdgpu_buffer_rsrc_t yrsrc =
@@ -829,15 +850,7 @@ __device__ __forceinline__ void conv_lds_tile(const ConvArgs& a, int tilesX, int
 #pragma unroll
   for (int half = 0; half < EPH; ++half) {
     const bool mine = grp == 0 && (EPH == 1 || (prow0 / HROWS) == half);  // this wave's rows belong to the half
-    if (!HEAD) {
-      const unsigned short* rb = res + pixb * a.Cout + co;
-#pragma unroll
-      for (int j = 0; j < EPJ; ++j) {
-        const int row = half * HROWS + j * RPJ;
-        rres[j] = make_uint4(0, 0, 0, 0);
-        if (res_vec && oyb + row < a.Ho) rres[j] = *reinterpret_cast<const uint4*>(rb + row * rstep);
-      }
-    }
+    if (!EARLY_RES) load_residual(half);
     if (mine) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {

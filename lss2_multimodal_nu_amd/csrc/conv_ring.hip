@@ -262,6 +262,7 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
       if (++slot == NSL) { slot = 0; ++gen; }
     }
     while (inflight > 0) publish_oldest();
+    rk_wait_vmcnt<0>();  // (see the patch loaders' exit)
     write_stats();
     return;
   }
@@ -436,6 +437,11 @@ __global__ __launch_bounds__(RK_NWAVES * 64, 3) void conv_ring_kernel(RingArgs a
         if (c + 1 < a.nch && c + 1 < nskip) prepare(c + 1);
       }
     }
+    // A loader wave must never reach s_endpgm with LDS-DMA in flight: once the workgroup's last wave is gone its LDS is
+    // handed to the next workgroup while the transfer still lands.  Every path above already ends behind a vmcnt(0)
+    // (each chunk's pieces are waited for before they are published); this one is free and keeps that true for any
+    // timing-only build that compiles waits out (the NOWAITW fault of round 3).
+    rk_wait_vmcnt<0>();
     write_stats();
     return;
   }

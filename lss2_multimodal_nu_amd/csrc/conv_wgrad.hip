@@ -141,6 +141,7 @@ __global__ __launch_bounds__((NTY * NTX + 1 + WK_NXL) * 64) void conv_wgrad_kern
       rk_add1(flags + F_FULL_X + slot, lane);
       if (++slot == a.nxs) { slot = 0; ++uses; }
     }
+    rk_wait_vmcnt<0>();  // never end a loader wave with LDS-DMA in flight (every fill above is already drained)
     return;
   }
 

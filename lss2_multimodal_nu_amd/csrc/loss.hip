@@ -166,14 +166,20 @@ __device__ __forceinline__ float hc_row_sum16(float v) {
   return v;
 }
 
-template <int K, bool BWD>
+// MODE 0 / 1: head + cross-entropy forward / backward (above).  MODE 2 / 3: the head ALONE, forward (logits written
+// NCHW fp32: `logits[(b K + k) HW + pix]`) and backward (g[p][k] read from the NCHW fp32 gradient of the logits): the
+// `up2[4]` of a training-mode `model(x)` call whose loss is computed elsewhere.  The library's convolution is not an
+// option there: its backward is not safe inside a HIP graph ("What the graph exposed").
+template <int K, int MODE>
 __global__ __launch_bounds__(256) void head_ce_kernel(const unsigned short* __restrict__ y,
                                                       const float* __restrict__ hw, const float* __restrict__ hb,
                                                       const long long* __restrict__ tgt,
                                                       const float* __restrict__ cw, long long M,
                                                       const float* __restrict__ sums, const float* __restrict__ gout,
                                                       float* __restrict__ part, unsigned short* __restrict__ dy,
-                                                      float* __restrict__ dw_part) {
+                                                      float* __restrict__ dw_part, float* __restrict__ logits_io,
+                                                      long long HW) {
+  constexpr bool BWD = MODE == 1 || MODE == 3, PLAIN = MODE >= 2;
   constexpr int CIN = 128, LPP = CIN / 8;  // lanes per pixel (16 = one DPP row)
   __shared__ float red[2][256];
   __shared__ float dwred[BWD ? 4 * K * CIN : 1];
@@ -188,8 +194,8 @@ __global__ __launch_bounds__(256) void head_ce_kernel(const unsigned short* __re
     for (int j = 0; j < 8; ++j) w[k][j] = hw[k * CIN + sub * 8 + j];
   float bias[K], clsw[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) { bias[k] = hb[k]; clsw[k] = cw[k]; }
-  const float gscale = BWD ? gout[0] / sums[1] : 0.f;
+  for (int k = 0; k < K; ++k) { bias[k] = hb[k]; clsw[k] = PLAIN ? 0.f : cw[k]; }
+  const float gscale = (BWD && !PLAIN) ? gout[0] / sums[1] : 0.f;
   float s_loss = 0.f, s_w = 0.f;
   float dwa[BWD ? K : 1][8];
   float dba[BWD ? K : 1];
@@ -214,6 +220,48 @@ __global__ __launch_bounds__(256) void head_ce_kernel(const unsigned short* __re
     for (int q = 0; q < 4; ++q) {
       yv[2 * q] = lss_bf2f((unsigned short)(ru[q] & 0xffff));
       yv[2 * q + 1] = lss_bf2f((unsigned short)(ru[q] >> 16));
+    }
+    if constexpr (PLAIN) {
+      const long long bimg = live ? p / HW : 0, pix = live ? p - bimg * HW : 0;
+      float* lp = logits_io + (size_t)bimg * K * HW + pix;
+      if constexpr (!BWD) {
+        // logits: lane `sub == k` of the pixel's row stores class k
+        float mine = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          float a = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a = fmaf(yv[j], w[k][j], a);
+          a = hc_row_sum16(a) + bias[k];
+          if (sub == k) mine = a;
+        }
+        if (live && sub < K) lp[(size_t)sub * HW] = mine;
+      } else {
+        float g[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) g[k] = live ? lp[(size_t)k * HW] : 0.f;
+        float dv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float a = 0.f;
+#pragma unroll
+          for (int k = 0; k < K; ++k) a = fmaf(g[k], w[k][j], a);
+          dv[j] = a;
+        }
+        if (live) {
+          uint4 o;
+          o.x = lss_pack_bf2(dv[0], dv[1]); o.y = lss_pack_bf2(dv[2], dv[3]);
+          o.z = lss_pack_bf2(dv[4], dv[5]); o.w = lss_pack_bf2(dv[6], dv[7]);
+          *reinterpret_cast<uint4*>(dy + (size_t)p * CIN + sub * 8) = o;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dwa[k][j] = fmaf(g[k], yv[j], dwa[k][j]);
+          if (sub == 0) dba[k] += g[k];
+        }
+      }
+      continue;
     }
     float logit[K];
     float mx = -INFINITY;
@@ -272,6 +320,7 @@ __global__ __launch_bounds__(256) void head_ce_kernel(const unsigned short* __re
       }
     }
   }
+  if (MODE == 2) return;
   if (!BWD) {
     red[0][tid] = s_loss;
     red[1][tid] = s_w;
@@ -349,11 +398,11 @@ extern "C" int lss_head_ce_fwd(const void* y, const float* head_w, const float* 
   const int grid = (int)((M + 15) / 16 > HC_BLOCKS ? HC_BLOCKS : (M + 15) / 16);
   const unsigned short* yp = reinterpret_cast<const unsigned short*>(y);
   if (K == 4)
-    hipLaunchKernelGGL((head_ce_kernel<4, false>), dim3(grid), dim3(256), 0, st, yp, head_w, head_b, target, class_w,
-                       M, nullptr, nullptr, workspace, nullptr, nullptr);
+    hipLaunchKernelGGL((head_ce_kernel<4, 0>), dim3(grid), dim3(256), 0, st, yp, head_w, head_b, target, class_w,
+                       M, nullptr, nullptr, workspace, nullptr, nullptr, nullptr, 0LL);
   else
-    hipLaunchKernelGGL((head_ce_kernel<8, false>), dim3(grid), dim3(256), 0, st, yp, head_w, head_b, target, class_w,
-                       M, nullptr, nullptr, workspace, nullptr, nullptr);
+    hipLaunchKernelGGL((head_ce_kernel<8, 0>), dim3(grid), dim3(256), 0, st, yp, head_w, head_b, target, class_w,
+                       M, nullptr, nullptr, workspace, nullptr, nullptr, nullptr, 0LL);
   hipLaunchKernelGGL(weighted_ce_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, grid, sums, loss);
   return lss_launch_status();
 }
@@ -372,11 +421,55 @@ extern "C" int lss_head_ce_bwd(const void* y, const float* head_w, const float* 
   const unsigned short* yp = reinterpret_cast<const unsigned short*>(y);
   unsigned short* dyp = reinterpret_cast<unsigned short*>(dy);
   if (K == 4)
-    hipLaunchKernelGGL((head_ce_kernel<4, true>), dim3(grid), dim3(256), 0, st, yp, head_w, head_b, target, class_w, M,
-                       sums, grad_loss, nullptr, dyp, workspace);
+    hipLaunchKernelGGL((head_ce_kernel<4, 1>), dim3(grid), dim3(256), 0, st, yp, head_w, head_b, target, class_w, M,
+                       sums, grad_loss, nullptr, dyp, workspace, nullptr, 0LL);
   else
-    hipLaunchKernelGGL((head_ce_kernel<8, true>), dim3(grid), dim3(256), 0, st, yp, head_w, head_b, target, class_w, M,
-                       sums, grad_loss, nullptr, dyp, workspace);
+    hipLaunchKernelGGL((head_ce_kernel<8, 1>), dim3(grid), dim3(256), 0, st, yp, head_w, head_b, target, class_w, M,
+                       sums, grad_loss, nullptr, dyp, workspace, nullptr, 0LL);
+  const int n = K * 128 + K;
+  hipLaunchKernelGGL(head_ce_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, st, workspace, grid, n, d_head_w,
+                     d_head_b, K * 128);
+  return lss_launch_status();
+}
+
+// The 1x1 head alone (ref src/modules.py:115, up2[4] = nn.Conv2d(128, outC, 1)), forward and backward, for a
+// training-mode forward whose loss is computed by the caller: y (M, 128) bf16 NHWC rows -> logits (B, K, H, W) fp32
+// NCHW (M = B * HW); backward: grad_logits (B, K, H, W) fp32 -> dy (M, 128) bf16, d_head_w (K, 128), d_head_b (K),
+// fixed-order partial sums (bit-reproducible).  workspace: lss_head_ce_workspace_bytes(K).
+extern "C" int lss_head1x1_fwd(const void* y, const float* head_w, const float* head_b, long long M, long long HW,
+                               int Cin, int K, float* logits, void* stream) {
+  LSS_CHECK_PTR(y); LSS_CHECK_PTR(head_w); LSS_CHECK_PTR(head_b); LSS_CHECK_PTR(logits);
+  if (M <= 0 || HW <= 0 || M % HW != 0 || Cin != 128 || (K != 4 && K != 8)) return LSS_E_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(y) & 15) != 0) return LSS_E_ALIGN;
+  const int grid = (int)((M + 15) / 16 > HC_BLOCKS ? HC_BLOCKS : (M + 15) / 16);
+  const unsigned short* yp = reinterpret_cast<const unsigned short*>(y);
+  hipStream_t st = lss_stream(stream);
+  if (K == 4)
+    hipLaunchKernelGGL((head_ce_kernel<4, 2>), dim3(grid), dim3(256), 0, st, yp, head_w, head_b, nullptr, nullptr, M,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, logits, HW);
+  else
+    hipLaunchKernelGGL((head_ce_kernel<8, 2>), dim3(grid), dim3(256), 0, st, yp, head_w, head_b, nullptr, nullptr, M,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, logits, HW);
+  return lss_launch_status();
+}
+
+extern "C" int lss_head1x1_bwd(const void* y, const float* head_w, const float* head_b, const float* grad_logits,
+                               long long M, long long HW, int Cin, int K, float* workspace, void* dy, float* d_head_w,
+                               float* d_head_b, void* stream) {
+  LSS_CHECK_PTR(y); LSS_CHECK_PTR(head_w); LSS_CHECK_PTR(head_b); LSS_CHECK_PTR(grad_logits); LSS_CHECK_PTR(workspace);
+  LSS_CHECK_PTR(dy); LSS_CHECK_PTR(d_head_w); LSS_CHECK_PTR(d_head_b);
+  if (M <= 0 || HW <= 0 || M % HW != 0 || Cin != 128 || (K != 4 && K != 8)) return LSS_E_SHAPE;
+  if (((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy)) & 15) != 0) return LSS_E_ALIGN;
+  const int grid = (int)((M + 15) / 16 > HC_BLOCKS ? HC_BLOCKS : (M + 15) / 16);
+  const unsigned short* yp = reinterpret_cast<const unsigned short*>(y);
+  hipStream_t st = lss_stream(stream);
+  float* gl = const_cast<float*>(grad_logits);  // read only (the kernel's logits pointer serves both modes)
+  if (K == 4)
+    hipLaunchKernelGGL((head_ce_kernel<4, 3>), dim3(grid), dim3(256), 0, st, yp, head_w, head_b, nullptr, nullptr, M,
+                       nullptr, nullptr, nullptr, reinterpret_cast<unsigned short*>(dy), workspace, gl, HW);
+  else
+    hipLaunchKernelGGL((head_ce_kernel<8, 3>), dim3(grid), dim3(256), 0, st, yp, head_w, head_b, nullptr, nullptr, M,
+                       nullptr, nullptr, nullptr, reinterpret_cast<unsigned short*>(dy), workspace, gl, HW);
   const int n = K * 128 + K;
   hipLaunchKernelGGL(head_ce_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, st, workspace, grid, n, d_head_w,
                      d_head_b, K * 128);

@@ -391,6 +391,8 @@ class GraphedTrainStep:
             self._replay()
             torch.cuda.synchronize()
             norms.append(float(self.grad_norm))
+            if os.environ.get("LSS_GRAPH_DEBUG"):
+                print("  self-check replay: pre-clip norm %.5g loss %.5f" % (norms[-1], float(self.loss)), flush=True)
         ok = all(n == n and 0.0 < n < float("inf") for n in norms) and max(norms) <= 20.0 * min(norms)
         if not ok:
             raise RuntimeError("replayed gradients are not stable (pre-clip norms %s): something in the step is not "

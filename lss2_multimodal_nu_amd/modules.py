@@ -871,7 +871,8 @@ class BevEncode(nn.Module):
                 torch._foreach_add_(counters, 1)
 
     def _forward_autograd(self, x):
-        return self.up2[4](self.features(x)).float()
+        from .tools import head_1x1  # (tools imports nothing from this module)
+        return head_1x1(self.features(x), self.up2[4]).float()
 
     def invalidate_plan(self):
         """Drop the cached launch lists (called whenever parameters may have changed)."""

@@ -1030,6 +1030,36 @@ def head_ce_bwd(y, head_w, head_b, target, class_w, sums, grad_loss):
     return dy, dw, db
 
 
+def head1x1_fwd(y, head_w, head_b):
+    """The 1x1 head alone: y (B, H, W, 128) contiguous bf16 -> logits (B, K, H, W) fp32 NCHW (lss_head1x1_fwd)."""
+    K, Cin = head_w.shape
+    if y.dtype != torch.bfloat16 or not y.is_contiguous() or y.dim() != 4 or y.shape[-1] != Cin:
+        raise ValueError("y must be a contiguous (B, H, W, %d) bf16 tensor" % Cin)
+    _f32c(head_w, "head_w", (K, Cin))
+    _f32c(head_b, "head_b", (K,))
+    B, H, W, _ = y.shape
+    out = torch.empty(B, K, H, W, dtype=torch.float32, device=y.device)
+    with _timed("head1x1_fwd"):
+        N.check(N.lib().lss_head1x1_fwd(N.ptr(y), N.ptr(head_w), N.ptr(head_b), B * H * W, H * W, Cin, K, N.ptr(out),
+                                        N.stream()), "lss_head1x1_fwd")
+    return out
+
+
+def head1x1_bwd(y, head_w, head_b, grad_logits):
+    """Backward of head1x1_fwd: grad_logits (B, K, H, W) fp32 contiguous -> (dy bf16 like y, d_head_w (K, Cin), d_head_b (K))."""
+    K, Cin = head_w.shape
+    B, H, W, _ = y.shape
+    _f32c(grad_logits, "grad_logits", (B, K, H, W))
+    dy = torch.empty_like(y)
+    dw = torch.empty(K, Cin, dtype=torch.float32, device=y.device)
+    db = torch.empty(K, dtype=torch.float32, device=y.device)
+    with _timed("head1x1_bwd"):
+        N.check(N.lib().lss_head1x1_bwd(N.ptr(y), N.ptr(head_w), N.ptr(head_b), N.ptr(grad_logits), B * H * W, H * W, Cin,
+                                        K, N.ptr(_head_ce_workspace(K, y.device)), N.ptr(dy), N.ptr(dw), N.ptr(db),
+                                        N.stream()), "lss_head1x1_bwd")
+    return dy, dw, db
+
+
 def pack_conv_weight_s2d(w_oihw, pad):
     """OIHW fp32 of a stride-2 k x k conv -> bf16 [tap'][Cout][4*Cin] for conv2d_s2_nhwc."""
     Cout, Cin, K, K2 = w_oihw.shape

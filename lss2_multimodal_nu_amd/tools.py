@@ -123,6 +123,44 @@ class _HeadCEFn(torch.autograd.Function):
         return (dy if dy.dtype == ydt else dy.to(ydt)), dw.view(wshape).to(wdt), db.to(bdt), None, None
 
 
+class _Head1x1Fn(torch.autograd.Function):
+    """`head(y)` for the 1x1 head `nn.Conv2d(128, K, 1)` (ref src/modules.py:115) on the HIP kernels, both ways: the
+    logits of a training-mode `model(x)` whose loss the caller computes (ref train.py:52, 62).  y: logical
+    (B, 128, H, W) tensor whose memory is NHWC bf16; returns (B, K, H, W) fp32.  Replaces torch's convolution there
+    because the library's backward is not safe inside a HIP graph: round 3's data-parallel graph step went wrong in
+    exactly this op."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias):
+        yn = y.permute(0, 2, 3, 1)
+        if yn.dtype != torch.bfloat16:
+            yn = yn.to(torch.bfloat16)
+        yn = yn.contiguous()
+        w2 = weight.detach().float().reshape(weight.shape[0], -1).contiguous()
+        b1 = bias.detach().float().contiguous()
+        out = ops.head1x1_fwd(yn, w2, b1)
+        ctx.save_for_backward(yn, w2, b1)
+        ctx.meta = (y.dtype, weight.shape, weight.dtype, bias.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        yn, w2, b1 = ctx.saved_tensors
+        ydt, wshape, wdt, bdt = ctx.meta
+        dy, dw, db = ops.head1x1_bwd(yn, w2, b1, g.float().contiguous())
+        dy = dy.permute(0, 3, 1, 2)
+        return (dy if dy.dtype == ydt else dy.to(ydt)), dw.view(wshape).to(wdt), db.to(bdt)
+
+
+def head_1x1(y, head):
+    """head(y) on the autograd path: the HIP head kernels when the shapes fit (128 input channels, 4 or 8 classes, a
+    bf16 activation on the GPU), torch's convolution otherwise (fp32 parity mode; NOT safe inside a HIP graph)."""
+    if (y.is_cuda and y.dtype == torch.bfloat16 and y.dim() == 4 and y.shape[1] == 128 and head.kernel_size == (1, 1)
+            and head.stride == (1, 1) and head.bias is not None and head.out_channels in (4, 8)):
+        return _Head1x1Fn.apply(y, head.weight, head.bias)
+    return head(y)
+
+
 def head_weighted_cross_entropy(y, head, ytgt, weight):
     """nn.CrossEntropyLoss(weight=weight)(head(y), ytgt) for a 1x1 `head` = nn.Conv2d(128, K, 1) applied to the
     (B, 128, H, W) activation y: fused into one HIP kernel per direction on the GPU when the shapes

@@ -166,7 +166,10 @@ def _b4_problem():
 
 # per-tensor gradient bounds by CLASS of tensor, set from what the step measures at batch 4 (every tensor's cosine is
 # written to gpurun_out/test_errors.txt by `report`): bf16 activations and gradients through 19 layers against fp32
-GRAD_COS = {"conv": 0.97, "bn": 0.93, "depthnet": 0.97, "head": 0.99}
+# (measured minima, round 4: conv 0.9729 [layer1.0.conv1], stem 0.9706, BatchNorm vectors 0.9675 [bn1.weight], depthnet
+# 0.9706, head 1.0000 - the stem, bn1 and the depthnet sit at the end of the longest backward chain; the step is
+# bit-reproducible, so these do not move from run to run)
+GRAD_COS = {"conv": 0.97, "stem": 0.96, "bn": 0.955, "depthnet": 0.96, "head": 0.999}
 
 
 def _tensor_class(name):
@@ -174,6 +177,8 @@ def _tensor_class(name):
         return "depthnet"
     if name.startswith("bevencode.up2.4."):
         return "head"
+    if name == "bevencode.conv1.weight":
+        return "stem"
     if ".bn" in name or "downsample.1." in name or name.endswith("bn1.weight") or name.endswith("bn1.bias") \
             or ".conv.1." in name or ".conv.4." in name or ".up2.2." in name:
         return "bn"
@@ -251,8 +256,7 @@ def test_benched_training_step_b4_vs_oracle(report):
 def test_benched_training_graph_replays_equal_eager_b4(report):
     """The batch-4 step as bench.py's train leg runs it - dp.GraphedTrainStep, one HIP graph - with a zero learning rate
     and frozen BatchNorm statistics: replay 1 and replay 3 must leave the gradients of the eager step of the same state,
-    bit for bit on every native unit (the two fp32 depthnet GEMMs of the lift-splat backward go to the BLAS library,
-    whose split sums may differ between a captured and an eager launch: 1e-5)."""
+    bit for bit."""
     from lss2_multimodal_nu_amd import dp
     B, sd0, feats, calib, tgt = _b4_problem()
     x, t = feats.cuda(), tgt.cuda()
@@ -274,9 +278,6 @@ def test_benched_training_graph_replays_equal_eager_b4(report):
         for n, p in m2.named_parameters():
             if p.grad is None:
                 continue
-            if n.startswith("bevencode."):
-                assert torch.equal(p.grad, ref[n]), (rep, n, float((p.grad - ref[n]).abs().max()))
-            else:
-                d = float((p.grad - ref[n]).abs().max()) / (float(ref[n].abs().max()) + 1e-30)
-                assert report("train_b4 graph replay %d vs eager, %s" % (rep, n), d) <= 1e-5, (rep, n, d)
+            # every gradient, the two depthnet tensors behind the BLAS library's GEMMs included (measured: 0.0)
+            assert torch.equal(p.grad, ref[n]), (rep, n, float((p.grad - ref[n]).abs().max()))
     ops.assert_no_timeouts("batch-4 graph replays")

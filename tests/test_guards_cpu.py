@@ -67,3 +67,19 @@ def test_graphed_step_refuses_a_capture_without_warm_up():
     from lss2_multimodal_nu_amd import dp
     with pytest.raises(ValueError, match="warm-up"):
         dp.GraphedTrainStep(None, None, None, None, torch.zeros(1), None, warmup=0)
+
+
+def test_profile_collector_refuses_tracebacks():
+    """tools/make_profiles.py never writes a tool's error text under profiles/ (round 3 committed five tracebacks)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_profiles", os.path.join(root, "tools", "make_profiles.py"))
+    mp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mp)
+    assert mp.refuse_traceback("up2 98.0 us 945 TF\n", "x").startswith("up2")
+    with pytest.raises(mp.BadEvidence):
+        mp.refuse_traceback("Traceback (most recent call last):\n  File ...\nAttributeError: liblss_STATS.so: undefined "
+                            "symbol: lss_conv2d_wgrad4x4_workspace_bytes\n", "ring_wait_stats.txt")
+    assert not [f for f in os.listdir(os.path.join(root, "profiles"))
+                if "Traceback" in open(os.path.join(root, "profiles", f), errors="ignore").read()]

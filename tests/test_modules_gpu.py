@@ -474,6 +474,47 @@ def test_histogram_guard_rezeroes_the_workspace_after_a_failed_call(model, golde
         assert torch.equal(model.get_voxels(x, *calib), good)
 
 
+@pytest.mark.parametrize("K", [4, 8])
+def test_head_1x1_native_vs_cpu_fp64(K, report):
+    """tools.head_1x1 (csrc/loss.hip head_ce_kernel MODE 2 / 3: `up2[4]` alone, forward and backward - what a
+    training-mode `model(x)` returns its logits through, ref src/modules.py:115) against torch's convolution in fp64 on
+    the CPU from the same bf16 activation; and bit-reproducible."""
+    import copy
+
+    from lss2_multimodal_nu_amd import ops
+    torch.manual_seed(40 + K)
+    B, H, W = 2, 37, 29
+    y = torch.randn(B, 128, H, W).bfloat16()
+    head = torch.nn.Conv2d(128, K, 1)
+    g = torch.randn(B, K, H, W)
+
+    def run():
+        yg = y.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        hg = copy.deepcopy(head).cuda()
+        spans = ops.KernelTimer(fine=True)
+        ops.set_timer(spans)
+        out = L.tools.head_1x1(yg, hg)
+        out.backward(g.cuda())
+        ops.set_timer(None)
+        assert {"head1x1_fwd", "head1x1_bwd"} <= set(spans.spans)
+        return out.detach(), yg.grad, hg.weight.grad, hg.bias.grad
+
+    out, dy, dw, db = run()
+    assert out.dtype == torch.float32 and out.shape == (B, K, H, W) and dy.dtype == torch.bfloat16
+    yr = y.double().requires_grad_(True)
+    hr = copy.deepcopy(head).double()
+    o = hr(yr)
+    o.backward(g.double())
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())  # noqa: E731
+    assert report("head_1x1 logits max rel err vs fp64, K=%d" % K, rel(out, o.detach())) <= 1e-5
+    assert report("head_1x1 dy max rel err (one bf16 rounding), K=%d" % K, rel(dy, yr.grad)) <= 2.0 ** -8
+    assert report("head_1x1 dW max rel err, K=%d" % K, rel(dw, hr.weight.grad)) <= 2e-4
+    assert report("head_1x1 db max rel err, K=%d" % K, rel(db, hr.bias.grad)) <= 2e-4
+    again = run()
+    for a, b in zip((out, dy, dw, db), again):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("K,shape", [(4, (2, 37, 50)), (8, (1, 9, 7)), (4, (4, 200, 200))])
 def test_fused_head_cross_entropy_vs_cpu_fp64(K, shape):
     """1x1 head + log-softmax + weighted NLL in one kernel per direction (csrc/loss.hip), against the
@@ -634,7 +675,7 @@ def test_training_step_vs_cpu_oracle_autograd(report):
     ref_loss.backward()
     e_loss = report("train_step loss rel err (bf16 GPU vs fp32 CPU oracle)", abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)))
     assert e_loss < 1e-2
-    worst, n, dots = 1.0, 0, [0.0, 0.0, 0.0]
+    worst, n, dots, failed = 1.0, 0, [0.0, 0.0, 0.0], []
     for name, p in m.named_parameters():
         g_ref = sd[name].grad
         assert (p.grad is None) == (g_ref is None), name
@@ -645,16 +686,24 @@ def test_training_step_vs_cpu_oracle_autograd(report):
         ratio = float(a.norm() / b.norm())
         worst = min(worst, cos)
         dots = [dots[0] + float(a @ b), dots[1] + float(a @ a), dots[2] + float(b @ b)]
-        # bf16 activations and gradients through 19 layers against fp32: lowest on the small per-channel vectors of the
-        # first layers (the longest backward chain; observed 0.943 on layer1.0.bn1.weight, 0.960 on the 7x7 stem,
-        # >= 0.97 on every other conv weight); the fp32 step below pins the structure tightly
-        assert cos > 0.90 and abs(ratio - 1) < 0.1, (name, cos, ratio)
+        # bf16 activations and gradients through 19 layers against fp32, ONE sample (the batch-4 form of this test,
+        # tests/test_bench_config_gpu.py, measures 0.967+ everywhere).  Bounds per CLASS of tensor, at what this step
+        # measures (each tensor's cosine goes to gpurun_out/test_errors.txt): the conv weights of the first layers 0.960
+        # (stem, layer1.0.conv1), the per-channel BatchNorm vectors 0.943 (end of the longest backward chain).  The native
+        # units' own tight pins are per kernel (tests/test_conv_grad_gpu.py: 2e-4 from bf16-rounded operands).
+        report("train_step grad cos " + name, cos)
+        bound = 0.95 if p.dim() == 4 else 0.93   # measured minima at ONE sample: 0.9600 (conv weights), 0.943 (BN vectors)
+        if not (cos > bound and abs(ratio - 1) < 0.1):
+            failed.append((name, cos, ratio, bound))
         n += 1
+    assert not failed, failed
     report("train_step min grad cosine vs oracle (bf16)", worst)
     whole = report("train_step cosine of the whole gradient vs oracle (bf16)", dots[0] / (dots[1] * dots[2]) ** 0.5)
     assert whole > 0.985
     assert n >= 50
-    # the same step in fp32 on the GPU: what is left against the oracle is summation order only
+    # the same step in fp32 on the GPU.  NOTE what this leg pins: without bf16 autocast `_native_training()` is off and the
+    # convolutions / BatchNorms are torch's library ops, so 0.9995 here checks the ORACLE's structure (ref
+    # src/modules.py:94-130) against an independent implementation - not one HIP training kernel.
     m32, loss32 = gpu_step(bf16=False)
     assert abs(float(loss32) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
     worst32 = 1.0

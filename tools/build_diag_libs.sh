@@ -4,6 +4,8 @@
 #   diag_libs/liblss_NOBLEND.so (-DRK_DIAG_NOBLEND: timing-only, the upsampled patch stays zero)
 # Use through LSS_HIP_LIB=<path>.  Run after `python -m lss2_multimodal_nu_amd.build_native`.
 set -e
+# always from the CURRENT objects of the shipped library: rebuild that first (no-op when nothing changed)
+python -m lss2_multimodal_nu_amd.build_native > /dev/null
 cd "$(dirname "$0")/../lss2_multimodal_nu_amd/csrc"
 mkdir -p ../../diag_libs /tmp/lss_diag
 for v in STATS NOBLEND NOWDMA "$@"; do
@@ -14,3 +16,4 @@ for v in STATS NOBLEND NOWDMA "$@"; do
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../diag_libs/liblss_$v.so $(ls build/*.o | grep -v conv_ring.o) /tmp/lss_diag/conv_ring_$v.o -ldl
 done
 ls -la ../../diag_libs
+python ../../tools/check_diag_abi.py

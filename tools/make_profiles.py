@@ -22,8 +22,23 @@ def find(d, pat):
     return g[-1] if g else None
 
 
+class BadEvidence(RuntimeError):
+    pass
+
+
+def refuse_traceback(text, what):
+    """A tool that died leaves a Python traceback where its numbers should be: such text never becomes a file under
+    profiles/ (round 3 committed five of them after an ABI change left diag_libs/ stale)."""
+    if "Traceback (most recent call last)" in text or "AttributeError:" in text or "undefined symbol" in text:
+        raise BadEvidence("%s: the tool's output is an error, not a measurement:\n%s" % (what, text[-600:]))
+    return text
+
+
 def run_tool(script, *args):
-    return subprocess.run([sys.executable, os.path.join(HERE, script)] + list(args), capture_output=True, text=True).stdout
+    r = subprocess.run([sys.executable, os.path.join(HERE, script)] + list(args), capture_output=True, text=True)
+    if r.returncode != 0:
+        raise BadEvidence("%s %s exited with %d:\n%s" % (script, " ".join(args), r.returncode, r.stderr[-600:]))
+    return refuse_traceback(r.stdout, script)
 
 
 def last_json_line(path):
@@ -34,10 +49,11 @@ def last_json_line(path):
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
     dst = os.path.join(ROOT, "profiles")
     w = lambda name, text: open(os.path.join(dst, "%s_%s" % (rnd, name)), "w").write(text)
+    bad = []
     for tag in ("bench_line", "bench_hires", "bench_fp32", "bench_config1"):
         p = os.path.join(src, tag + ".json")
         if os.path.exists(p) and os.path.getsize(p):
@@ -82,8 +98,14 @@ def main():
                      ("wgrad_microbench.txt", "wgrad_microbench.txt")):
         p = os.path.join(src, tag)
         if os.path.exists(p):
-            w(out, "".join(ln for ln in open(p) if "amdgpu.ids" not in ln))
+            try:
+                w(out, refuse_traceback("".join(ln for ln in open(p) if "amdgpu.ids" not in ln), tag))
+            except BadEvidence as e:
+                bad.append(str(e))
     print("\n".join(sorted(os.listdir(dst))))
+    if bad:
+        sys.stderr.write("\n".join(["REFUSED (not written to profiles/):"] + bad) + "\n")
+        raise SystemExit(2)
 
 
 if __name__ == "__main__":

@@ -5,7 +5,10 @@
 # Counters are collected in their own passes (--kernel-trace + --pmc only), as the pool requires.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
+# the diagnostic builds must carry the ABI of the shipped library (built together by tools/build_diag_libs.sh in the
+# build container, BEFORE the gpurun call): a stale one would leave tracebacks where measurements belong
+python $R/tools/check_diag_abi.py || { echo "diag_libs/ do not match liblss_hip.so: run tools/build_diag_libs.sh STATS NOBLEND NOWDMA READSONLY ONEREAD first"; exit 1; }
 OUT=$R/gpurun_out/prof_$ROUND
 rm -rf "$OUT" && mkdir -p "$OUT"
 ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-train --no-two-streams"  # profiled runs: the single-stream loop only
