@@ -466,6 +466,28 @@ int lss_lift_splat_from_heads(const float* frustum, const float* inv_post_rots, 
                               int X, int Y, int Z, int32_t* voxel, int32_t* vox_count, int32_t* vox_list,
                               int32_t* entries, int32_t* cursor, void* bev, int layout, void* stream);
 
+/* Descriptor form of lss_lift_splat_forward / _hostcal / _from_heads (same replaced reference lines:
+ * src/model_BEV_TXT.py:50-126 get_geometry + get_cam_feats + voxel_pooling, src/modules.py:82-84, src/tools.py:181-218),
+ * with one more workspace: `direct_entries` (lss_lift_splat_direct_bytes(...) bytes, 8-byte aligned, contents
+ * irrelevant).  With it the region pipeline runs as TWO launches - the geometry workgroups write their points straight
+ * into fixed-capacity per-region buckets, the splat gathers the depth weights itself - instead of three (no fill
+ * launch).  A region that overflows its bucket (degenerate calibrations only) is rebuilt from the voxel ids: results
+ * are the exact, order-independent fixed-point sums either way.  NULL / too small: the three-launch form.
+ *   calib_host != NULL : host calibration, B*N <= 36 (inv_post_rots .. trans ignored), f32 depthnet math only
+ *   x == NULL          : depth (B*N, D, fH, fW) and feat (B*N*fH*fW, C) are INPUTS (the vovnet heads' form) */
+typedef struct lss_lift_splat_desc {
+  const float *frustum, *inv_post_rots, *post_trans, *combine, *trans, *calib_host, *dx, *bx;
+  const float *x, *w, *bias;
+  int32_t *voxel, *vox_count, *vox_list, *entries, *cursor;
+  void* direct_entries;
+  unsigned long long direct_bytes;
+  float *depth, *feat;
+  void* bev;
+  int32_t B, N, D, fH, fW, Cin, C, X, Y, Z, layout, math;
+} lss_lift_splat_desc_t;
+size_t lss_lift_splat_direct_bytes(int B, int N, int D, int fH, int fW, int C, int X, int Y, int Z);
+int lss_lift_splat_forward_desc(const lss_lift_splat_desc_t* desc, void* stream);
+
 /* 1 when lss_lift_splat_forward (f32 depthnet math) runs (B,N,D,fH,fW,C | X,Y,Z) on the region-bucketed pipeline
  * (K2 || K3 with LDS region histograms -> region fill -> fixed-point region splat), 0 when the problem exceeds its
  * limits and the voxel-list pipeline (K3, K4, K2, K5) is used.  Honours LSS_SPLAT_LEGACY. */

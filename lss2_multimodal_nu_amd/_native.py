@@ -81,6 +81,8 @@ SIGNATURES = {
     "lss_lift_splat_forward": (_i, [_vp] * 10 + [_i] * 10 + [_vp] * 8 + [_i, _i, _vp]),
     "lss_region_pipeline_ok": (_i, [_i] * 9),
     "lss_lift_splat_from_heads": (_i, [_vp] * 9 + [_i] * 9 + [_vp] * 6 + [_i, _vp]),
+    "lss_lift_splat_direct_bytes": (_sz, [_i] * 9),
+    "lss_lift_splat_forward_desc": (_i, [_vp, _vp]),
     "lss_head_ce_workspace_bytes": (_sz, [_i]),
     "lss_head_ce_fwd": (_i, [_vp] * 5 + [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp]),
     "lss_head_ce_bwd": (_i, [_vp] * 5 + [ctypes.c_longlong, _i, _i] + [_vp] * 7),
@@ -104,6 +106,16 @@ class ConvLaunch(ctypes.Structure):
                                    "head_w", "head_b", "head_out", "y2")] + \
                [(n, ctypes.c_int32) for n in ("B", "H", "W", "Cx", "C2", "up", "Cout", "KH", "KW", "stride", "pad",
                                               "relu", "dt", "head_n", "kind", "split")]
+
+
+class LiftSplatDesc(ctypes.Structure):
+    """lss_lift_splat_desc_t of include/lss_hip.h."""
+    _fields_ = [(n, _vp) for n in ("frustum", "inv_post_rots", "post_trans", "combine", "trans", "calib_host", "dx", "bx",
+                                   "x", "w", "bias", "voxel", "vox_count", "vox_list", "entries", "cursor",
+                                   "direct_entries")] + \
+               [("direct_bytes", ctypes.c_ulonglong)] + \
+               [(n, _vp) for n in ("depth", "feat", "bev")] + \
+               [(n, ctypes.c_int32) for n in ("B", "N", "D", "fH", "fW", "Cin", "C", "X", "Y", "Z", "layout", "math")]
 
 
 _lib = None

@@ -30,7 +30,8 @@ __device__ __forceinline__ float row_dot(const float* m, float p0, float p1, flo
 __device__ __forceinline__ int quantise_point(float g0, float g1, float g2,
                                               const float* __restrict__ dx,
                                               const float* __restrict__ bx, int b, int X, int Y,
-                                              int Z, int* region_xy = nullptr, int nRy = 0) {
+                                              int Z, int* region_xy = nullptr, int nRy = 0,
+                                              int* cell_in_region = nullptr) {
   const float d0 = dx[0], d1 = dx[1], d2 = dx[2];
   const float lo0 = __fsub_rn(bx[0], __fmul_rn(d0, 0.5f));
   const float lo1 = __fsub_rn(bx[1], __fmul_rn(d1, 0.5f));
@@ -43,6 +44,7 @@ __device__ __forceinline__ int quantise_point(float g0, float g1, float g2,
   if (!kept) return -1;
   const int ix = (int)u0, iy = (int)u1, iz = (int)u2;  // v_cvt_i32_f32 truncates
   if (region_xy) *region_xy = (ix >> 3) * nRy + (iy >> 3);  // RS = 8 cells per region side
+  if (cell_in_region) *cell_in_region = (((ix & 7) << 3) | (iy & 7)) * Z + iz;
   return ((b * X + ix) * Y + iy) * Z + iz;
 }
 
@@ -81,6 +83,8 @@ struct RegionArgs {
   int32_t* region_start;  // [B*rps] exclusive scan over (sample, region), written by the fill kernel
   float* wg_absmax;       // [n2 + 1] max |feature| per K2 workgroup (plain stores); [n2] = their maximum (fill)
   int nRy, rps;
+  int2* dentries;         // DIRECT form (region_plan.h): the geometry workgroups write the entries; else nullptr
+  int cap, HW;            // slots per region; pixels per camera image
 };
 
 // one thread per frustum point of camera image bn; tile_x = 256-point block within the image.
@@ -96,7 +100,7 @@ __device__ __forceinline__ void points_to_voxels_body(
     for (int i = threadIdx.x; i < rg->rps; i += 256) hist[i] = 0;
     __syncthreads();
   }
-  int v = -2, region = 0;  // -2: no point for this thread
+  int v = -2, region = 0, cell = 0;  // -2: no point for this thread
   if (f < DHW) {
   Mat3 ipr, cmb;  // block-uniform -> scalar loads
 #pragma unroll
@@ -127,19 +131,36 @@ __device__ __forceinline__ void points_to_voxels_body(
     float* gp = geom + ((size_t)bn * DHW + f) * 3;
     gp[0] = g0; gp[1] = g1; gp[2] = g2;
   }
-  v = quantise_point(g0, g1, g2, dx, bx, bn / Ncam, X, Y, Z, &region, rg ? rg->nRy : 0);
+  v = quantise_point(g0, g1, g2, dx, bx, bn / Ncam, X, Y, Z, &region, rg ? rg->nRy : 0, &cell);
   if (v >= 0 && vox_count) atomicAdd(vox_count + v, 1);
   voxel[(size_t)bn * DHW + f] = v;
   }
   if (hist != nullptr) {
     const int b = bn / Ncam;
-    if (v >= 0) atomicAdd(&hist[region], 1);  // ds_add_u32
+    const bool direct = rg->dentries != nullptr;
+    int rank = 0;
+    if (v >= 0) rank = atomicAdd(&hist[region], 1);  // ds_add(_rtn)_u32: count, and this point's rank in its group
     __syncthreads();
     // one global atomic per non-empty (workgroup, region); nothing per sample: ~700 workgroups adding to the
-    // same word serialise at ~11 ns each (measured: +10 us on this launch), the fill kernel sums the counts instead
+    // same word serialise at ~11 ns each (measured: +10 us on this launch), the fill kernel sums the counts instead.
+    // DIRECT form: the same atomic RETURNS the group's base slot in the region's bucket.
     for (int i = threadIdx.x; i < rg->rps; i += 256) {
       const int c = hist[i];
-      if (c > 0) atomicAdd(rg->region_count + b * rg->rps + i, c);
+      if (c > 0) {
+        const int base = atomicAdd(rg->region_count + b * rg->rps + i, c);
+        if (direct) hist[i] = base;
+      }
+    }
+    if (direct) {
+      __syncthreads();
+      if (v >= 0) {
+        const int slot = hist[region] + rank;
+        if (slot < rg->cap) {  // (a fuller region keeps only its count: the splat takes it from the voxel ids)
+          const int d = f / rg->HW, pix = f - d * rg->HW;
+          rg->dentries[(size_t)(b * rg->rps + region) * rg->cap + slot] =
+              make_int2(((bn * rg->HW + pix) << 8) | cell, bn * DHW + f);
+        }
+      }
     }
   }
 }
@@ -172,6 +193,7 @@ struct FusedK2K3Args {
   int use_regions;
   unsigned long long* stamps;  // LSS_L1_STAMPS=<hex device address, 8 u64 per workgroup>: s_memrealtime phase stamps
   int diag;  // timing-only builds (LSS_K2K3_DIAG): 1 = the K2 blocks return at once, 2 = the K3 blocks do
+  int k2_xcd;  // XCD-aware order of the row-split depthnet workgroups (LSS_K2_XCD=0: id order, for A/B)
   RegionArgs rg;
 };
 
@@ -220,7 +242,17 @@ __global__ __launch_bounds__(256, 3) void depthnet_rows_and_voxels_kernel(FusedK
   unsigned long long* st = a.stamps ? a.stamps + (size_t)id * 8 : nullptr;
   if (st != nullptr && threadIdx.x == 0) st[0] = __builtin_amdgcn_s_memrealtime();
   if (id < n2x) {
-    const int k2 = id, tile = k2 >> 1;
+    // XCD-aware order of the depthnet workgroups (cdna_hip_programming.md T1): workgroups are dealt round-robin to the 8
+    // XCDs, so XCD k takes the k-th contiguous eighth of the (tile, row half) list = whole camera images.  The two row
+    // halves of a pixel tile read the same x lines, and so do neighbouring tiles (a 128-B line of x holds 32 pixels of
+    // one channel and a tile is 16): in id order those four workgroups sat on four XCDs and each L2 fetched the lines
+    // for itself - FETCH_SIZE 37 MB for 8.9 MB of trunk features (profiles/r03_hbm_traffic.json).
+    int k2 = id;
+    if (a.k2_xcd) {
+      const int xcd = id & 7, q8 = n2x >> 3, r8 = n2x & 7;
+      k2 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+    }
+    const int tile = k2 >> 1;
     if ((k2 & 1) == 0)
       lss_depthnet::depthnet_rows_f32_body<ND>(a.x, a.w, a.bias, 0, a.D, true, a.Cin, a.HW, a.D, a.C, a.depth, a.feat,
                                                tile % a.gx2, tile / a.gx2, lds, nullptr, st);
@@ -536,6 +568,7 @@ static int depthnet_voxels_impl(const float* frustum, const float* inv_post_rots
   a.voxel = voxel; a.vox_count = vox_count;
   a.use_regions = plan != nullptr;
   a.diag = getenv("LSS_K2K3_DIAG") ? atoi(getenv("LSS_K2K3_DIAG")) : 0;
+  a.k2_xcd = getenv("LSS_K2_XCD") == nullptr || atoi(getenv("LSS_K2_XCD")) != 0;
   a.stamps = getenv("LSS_L1_STAMPS") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("LSS_L1_STAMPS"), nullptr, 16))
                                      : nullptr;
   if (plan != nullptr) {
@@ -543,8 +576,9 @@ static int depthnet_voxels_impl(const float* frustum, const float* inv_post_rots
     a.rg.region_count = plan->region_count; a.rg.region_cursor = plan->region_cursor;
     a.rg.region_start = plan->region_start;
     a.rg.wg_absmax = plan->wg_absmax; a.rg.nRy = plan->nRy; a.rg.rps = plan->rps;
+    a.rg.dentries = reinterpret_cast<int2*>(plan->dentries); a.rg.cap = plan->cap; a.rg.HW = fH * fW;
   } else {
-    a.rg = RegionArgs{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    a.rg = RegionArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0};
   }
   a.gx3 = lss_cdiv(DHW, 256);
   const long long nblk = (long long)a.n2 + (long long)a.gx3 * B * N;
@@ -675,6 +709,7 @@ int lss_region_voxels_absmax(const float* frustum, const float* inv_post_rots, c
   a.voxel = voxel; a.vox_count = nullptr; a.use_regions = 1;
   a.rg.region_count = plan.region_count; a.rg.region_cursor = plan.region_cursor; a.rg.region_start = plan.region_start;
   a.rg.wg_absmax = plan.wg_absmax; a.rg.nRy = plan.nRy; a.rg.rps = plan.rps;
+  a.rg.dentries = reinterpret_cast<int2*>(plan.dentries); a.rg.cap = plan.cap; a.rg.HW = fH * fW;
   a.gx3 = lss_cdiv(DHW, 256);
   const long long nblk = (long long)a.n2 + (long long)a.gx3 * B * N;
   if (nblk >= (1LL << 31)) return LSS_E_SHAPE;
@@ -693,7 +728,7 @@ int lss_region_fill(const int32_t* voxel, const float* depth, int B, int N, int 
   if (LSS_REGION_SIDE * LSS_REGION_SIDE * Z > 256 || (long long)B * N * HW >= (1LL << 23) || B * N > 65535)
     return LSS_E_SHAPE;
   if ((reinterpret_cast<uintptr_t>(entries) & 7) != 0) return LSS_E_ALIGN;
-  RegionArgs rg{plan.region_count, plan.region_cursor, plan.region_start, plan.wg_absmax, plan.nRy, plan.rps};
+  RegionArgs rg{plan.region_count, plan.region_cursor, plan.region_start, plan.wg_absmax, plan.nRy, plan.rps, nullptr, 0, HW};
   const size_t lds_bytes = (size_t)2 * plan.rps * sizeof(int);
   if (lds_bytes > 64 * 1024) return LSS_E_SHAPE;
   dim3 grid(lss_cdiv(DHW, 256), B * N);

@@ -2,6 +2,9 @@
 //   launch 1  K2 || K3   depthnet + softmax  ||  frustum points -> voxel ids + per-region LDS histograms
 //   launch 2  fill       per-(workgroup, region) slot reservation, entries grouped by region
 //   launch 3  splat      one workgroup per region: LDS fixed-point segmented sums -> coalesced BEV stores
+// DIRECT form (two launches, when the caller hands over the larger entry workspace): launch 1's geometry workgroups
+// reserve their slots in the regions' fixed-capacity buckets with the one global atomic per (workgroup, region) they
+// issue anyway and write the entries; the fill launch and its kernel boundary (6.6 + ~1.5 us of a 45-us level) go.
 // geom_bucket.hip implements launches 1-2, splat.hip launch 3 and the dispatch.
 #pragma once
 #include <stdint.h>
@@ -12,6 +15,12 @@ struct LssRegionPlan {
   int32_t* region_start;   // [B*rps]
   float* wg_absmax;        // [n2 + 1]: per K2 workgroup, and their maximum (written by the fill kernel)
   int nRx, nRy, rps, n2;
+  // DIRECT form (round 4; dentries != nullptr): launch 1 writes the entries itself, at FIXED per-region offsets -
+  // region r owns dentries[r * cap .. (r + 1) * cap) as {(feature row << 8) | cell in region, point id} - and launch 2
+  // (the fill) does not exist: the splat reads region_count[r], its slots, and depth[point id].  A region with more
+  // than `cap` points keeps only its count; the splat then takes that region from the voxel ids of its sample.
+  int32_t* dentries;
+  int cap;
 };
 
 constexpr int LSS_REGION_SIDE = 8;  // cells per region side

@@ -306,11 +306,69 @@ __device__ __forceinline__ void region_accumulate_careful(const float* __restric
 // (An fp32 tile updated with ds_add_f32 - 7 instructions per point instead of 12 - was built and measured: 92.8 us
 // against 20.1 us for this kernel on the bench workload.  LDS float atomics are an order of magnitude slower than
 // the 64-bit integer ones on gfx950, so the fixed-point form is the fast one as well as the reproducible one.)
-template <int CPL, int LAYOUT>
+// DIRECT (region_plan.h): the entries of region r sit at r * cap as {key, point id} - written by launch 1 itself, no
+// fill launch, no region_start - and the depth weight is gathered from depth[point id] beside the entry load; the
+// maximum over K2's per-workgroup |feature| maxima (what the fill kernel's first workgroup used to reduce) is taken
+// by every workgroup from the n2 slots (1 KB, L2-resident) while its other loads fly.  A region whose count exceeds
+// `cap` is rebuilt from the voxel ids of its sample (region_accumulate_scan): exact, slow, and only reachable with
+// degenerate calibrations.
+struct DirectArgs {
+  const float* depth;      // (B*N, D, HW): flat index = point id
+  const int32_t* voxel;    // point id -> voxel id or -1
+  int Ncam, DHW, HW;
+};
+
+// every point of sample b whose voxel lies in region (rx, ry): the careful (flagging) accumulation, element by element
+template <int CPL>
+__device__ __forceinline__ void region_accumulate_scan(const float* __restrict__ feat, const DirectArgs& da, int b,
+                                                       int rx, int ry, int X, int Y, int Z, double scale, float limit,
+                                                       unsigned long long* tile, unsigned int* flags, int wave,
+                                                       int lane) {
+  constexpr int C = 64 * CPL;
+  const int np = da.Ncam * da.DHW;  // points of one sample
+  for (int p0 = wave * 64; p0 < np; p0 += 256) {
+    const int pl = p0 + lane;
+    int key = -1;
+    float w = 0.f;
+    if (pl < np) {
+      const int p = b * np + pl;
+      const int v = da.voxel[p];
+      if (v >= 0) {
+        const int iz = v % Z, cxy = v / Z - b * X * Y;
+        const int ix = cxy / Y, iy = cxy - ix * Y;
+        if ((ix >> 3) == rx && (iy >> 3) == ry) {
+          const int bn = p / da.DHW, f = p - bn * da.DHW, pix = f % da.HW;
+          key = ((bn * da.HW + pix) << 8) | ((((ix & 7) << 3) | (iy & 7)) * Z + iz);
+          w = da.depth[p];
+        }
+      }
+    }
+    unsigned long long todo = __ballot(key >= 0);
+    while (todo) {
+      const int i = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const int k = __builtin_amdgcn_readlane(key, i);
+      const float ww = rl_f(w, i);
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        const float x = ww * feat[(size_t)(k >> 8) * C + q * 64 + lane];
+        const int o = (k & 255) * C + q * 64 + lane;
+        if (!(fabsf(x) < limit)) {
+          atomicOr(&flags[o >> 5], 1u << (o & 31));
+        } else {
+          const double t = __builtin_fma((double)x, scale, FX_MAGIC);
+          atomicAdd(&tile[o], (unsigned long long)(__builtin_bit_cast(long long, t) - ((long long)FX_MAGIC_HI << 32)));
+        }
+      }
+    }
+  }
+}
+
+template <int CPL, int LAYOUT, bool DIRECT = false>
 __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restrict__ feat,
                                                            const int2* __restrict__ entries, LssRegionPlan rp,
                                                            int X, int Y, int Z, void* __restrict__ bev_,
-                                                           unsigned long long* stamps, int centre_out) {
+                                                           unsigned long long* stamps, int centre_out, DirectArgs da) {
   constexpr int C = 64 * CPL;
   // LSS_L1_STAMPS diagnostic: s_memrealtime at entry / tile cleared / sums complete / stores issued; word 4 = points
   unsigned long long* const stp = stamps ? stamps + (size_t)blockIdx.x * 8 : nullptr;
@@ -332,14 +390,26 @@ __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restri
   const int r = b * rp.rps + rx * rp.nRy + ry;
   const int ncell = RSIDE * RSIDE * Z;
   unsigned int* flags = reinterpret_cast<unsigned int*>(tile + (size_t)ncell * C);  // [ncell*C/32]
-  const int n = rp.region_count[r];
-  const int start = rp.region_start[r];
-  const float m = rp.wg_absmax[rp.n2];  // max FINITE |feature| over K2's workgroups (reduced by the fill kernel)
+  __shared__ float wave_absmax[4];
+  const int ntot = rp.region_count[r];                       // points of the region
+  const bool over = DIRECT && ntot > rp.cap;                 // more than its bucket holds: taken from the voxel ids
+  const int n = DIRECT ? (over ? 0 : ntot) : ntot;           // entries to stream
+  const int start = DIRECT ? r * rp.cap : rp.region_start[r];
+  float m;  // max FINITE |feature| over K2's workgroups
+  if (DIRECT) {
+    float mm = 0.f;
+    for (int i = tid; i < rp.n2; i += 256) mm = fmaxf(mm, rp.wg_absmax[i]);
+    mm = lss_wave_max(mm);
+    if (lane == 0) wave_absmax[wave] = mm;
+  } else {
+    m = rp.wg_absmax[rp.n2];  // (reduced by the fill kernel)
+  }
   if (tid == 0) wg_watch = 0;
   __syncthreads();  // every thread has read region_count[r]
+  if (DIRECT) m = fmaxf(fmaxf(wave_absmax[0], wave_absmax[1]), fmaxf(wave_absmax[2], wave_absmax[3]));
   if (tid == 0) {   // the counters go back to zero (workspace contract)
     rp.region_count[r] = 0;
-    rp.region_cursor[r] = 0;
+    if (!DIRECT) rp.region_cursor[r] = 0;
   }
   // Every finite product is |depth weight (<= 1) x feature| <= m < 2^e, so |x * 2^(40-e)| < 2^40: far inside the
   // 2^51 the magic-number conversion holds.  A product at or above 2^(e+10) can only come from a non-finite operand
@@ -363,7 +433,7 @@ __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restri
     if (lane < chunk && c0 + lane < n) {
       const int2 en = entries[start + c0 + lane];
       key = en.x;
-      w = __builtin_bit_cast(float, en.y);
+      w = DIRECT ? da.depth[en.y] : __builtin_bit_cast(float, en.y);
     }
     for (int i = tid; i < zero_n; i += 256) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -406,7 +476,7 @@ __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restri
       if (c0 < n && lane < chunk && c0 + lane < n) {
         const int2 en = entries[start + c0 + lane];
         key = en.x;
-        w = __builtin_bit_cast(float, en.y);
+        w = DIRECT ? da.depth[en.y] : __builtin_bit_cast(float, en.y);
       }
     }
     if (watch >= watch_limit) atomicOr(&wg_watch, 1u);  // a non-finite (or impossibly large) product went by
@@ -416,10 +486,19 @@ __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restri
       __syncthreads();
       for (int i = tid; i < zero_n; i += 256) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
       __syncthreads();
-      region_accumulate_careful<CPL>(feat, entries, start, n, scale, ldexpf(1.0f, min(e + 10, 127)), tile, flags, wave, lane);
+      if (DIRECT)
+        region_accumulate_scan<CPL>(feat, da, b, rx, ry, X, Y, Z, scale, ldexpf(1.0f, min(e + 10, 127)), tile, flags, wave, lane);
+      else
+        region_accumulate_careful<CPL>(feat, entries, start, n, scale, ldexpf(1.0f, min(e + 10, 127)), tile, flags, wave, lane);
       __syncthreads();
     }
+  } else if (over) {  // DIRECT, bucket overflow: the whole region from the voxel ids of its sample
+    for (int i = tid; i < zero_n; i += 256) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    region_accumulate_scan<CPL>(feat, da, b, rx, ry, X, Y, Z, scale, ldexpf(1.0f, min(e + 10, 127)), tile, flags, wave, lane);
+    __syncthreads();
   }
+  const bool any = n > 0 || over;  // the tile holds sums
 
   auto value = [&](int o) -> float {  // (cell, channel) element o of the tile as fp32
     // int64 -> fp32 on the fp32 pipe: hi * 2^32 * 2^-s + lo * 2^-s (hi, lo the two words).  |sum| < 2^56 (terms below
@@ -441,7 +520,7 @@ __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restri
       if (ix >= X) continue;
       float v[RSIDE];
 #pragma unroll
-      for (int ly = 0; ly < RSIDE; ++ly) v[ly] = n > 0 ? value(((lx * RSIDE + ly) * Z + iz) * C + c) : 0.f;
+      for (int ly = 0; ly < RSIDE; ++ly) v[ly] = any ? value(((lx * RSIDE + ly) * Z + iz) * C + c) : 0.f;
       float* op = bev + (((size_t)b * Z + iz) * C + c) * X * Y + (size_t)ix * Y + iy0;
       if (vec_ok) {
         *reinterpret_cast<f32x4*>(op) = (f32x4){v[0], v[1], v[2], v[3]};
@@ -461,7 +540,7 @@ __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restri
       if (ix >= X || iy >= Y) continue;
       float v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = n > 0 ? value(cell * C + c8 * 8 + k) : 0.f;
+      for (int k = 0; k < 8; ++k) v[k] = any ? value(cell * C + c8 * 8 + k) : 0.f;
       const size_t o = ((((size_t)b * X + ix) * Y + iy) * Z + iz) * C + c8 * 8;
       if (LAYOUT == LSS_BEV_NHWC_F32) {
         float* bev = reinterpret_cast<float*>(bev_);
@@ -479,7 +558,7 @@ __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restri
     __syncthreads();
     if (tid == 0) {
       stp[3] = __builtin_amdgcn_s_memrealtime();
-      stp[4] = (unsigned long long)n;
+      stp[4] = (unsigned long long)ntot;
     }
   }
 }
@@ -637,8 +716,14 @@ extern "C" int lss_lift_splat_bwd(const void* grad_bev, int layout, const int32_
 
 // Can the region-bucketed pipeline run this problem out of the ABI's workspace?  (vox_count: the zero-between-
 // calls words; vox_list: plain scratch.)  Otherwise the voxel-list pipeline below is used.
+constexpr int LSS_DIRECT_CAP = 1024;     // slots per region of the direct form (the busiest region of the benched rigs
+constexpr int LSS_DIRECT_MIN_CAP = 256;  // holds ~410 points); below this capacity the three-launch form is used instead
+
 static bool region_plan_for(int B, int N, int D, int fH, int fW, int C, int X, int Y, int Z, int32_t* vox_count,
-                            int32_t* vox_list, LssRegionPlan* rp) {
+                            int32_t* vox_list, LssRegionPlan* rp, void* direct_entries = nullptr,
+                            unsigned long long direct_bytes = 0) {
+  rp->dentries = nullptr;
+  rp->cap = 0;
   if (const char* e = getenv("LSS_SPLAT_LEGACY"))
     if (atoi(e) != 0) return false;
   const long long nvox = (long long)B * X * Y * Z, P = (long long)B * N * D * fH * fW;
@@ -659,7 +744,27 @@ static bool region_plan_for(int B, int N, int D, int fH, int fW, int C, int X, i
   rp->region_cursor = vox_count + nreg;
   rp->region_start = vox_list;
   rp->wg_absmax = reinterpret_cast<float*>(vox_list + nreg);
+  // the direct form: as many slots per region as the caller's workspace holds, at most LSS_DIRECT_CAP
+  if (direct_entries != nullptr && (reinterpret_cast<uintptr_t>(direct_entries) & 7) == 0 &&
+      !(getenv("LSS_SPLAT_DIRECT") != nullptr && atoi(getenv("LSS_SPLAT_DIRECT")) == 0)) {
+    long long cap = (long long)(direct_bytes / 8) / nreg;
+    if (cap > LSS_DIRECT_CAP) cap = LSS_DIRECT_CAP;
+    cap &= ~7LL;
+    if (cap >= LSS_DIRECT_MIN_CAP && nreg * cap < (1LL << 31)) {
+      rp->dentries = reinterpret_cast<int32_t*>(direct_entries);
+      rp->cap = (int)cap;
+    }
+  }
   return true;
+}
+
+// Bytes of the direct form's entry workspace for this problem (0: the region pipeline does not take it at all).
+extern "C" size_t lss_lift_splat_direct_bytes(int B, int N, int D, int fH, int fW, int C, int X, int Y, int Z) {
+  if (B <= 0 || N <= 0 || D <= 0 || fH <= 0 || fW <= 0 || X <= 0 || Y <= 0 || Z <= 0 || (C != 64 && C != 128)) return 0;
+  static int32_t dummy[4];
+  LssRegionPlan rp;
+  if (!region_plan_for(B, N, D, fH, fW, C, X, Y, Z, dummy, dummy, &rp)) return 0;
+  return (size_t)B * rp.rps * LSS_DIRECT_CAP * 8;
 }
 
 // Does lss_lift_splat_forward run this problem on the region-bucketed pipeline (f32 depthnet math assumed)?  The same
@@ -672,7 +777,11 @@ extern "C" int lss_region_pipeline_ok(int B, int N, int D, int fH, int fW, int C
 }
 
 static int region_splat_launch(const float* feat, const int32_t* entries, const LssRegionPlan& rp, int B, int C, int X,
-                               int Y, int Z, void* bev, int layout, hipStream_t st) {
+                               int Y, int Z, void* bev, int layout, hipStream_t st, const DirectArgs* dap = nullptr) {
+  const bool direct = rp.dentries != nullptr;
+  if (direct && dap == nullptr) return LSS_E_NULL;
+  const DirectArgs da = direct ? *dap : DirectArgs{nullptr, nullptr, 0, 0, 0};
+  if (direct) entries = rp.dentries;
   const size_t lds = (size_t)64 * Z * C * 8 + (size_t)64 * Z * C / 8;
   dim3 grid(B * rp.rps);
   const int2* en = reinterpret_cast<const int2*>(entries);
@@ -687,14 +796,20 @@ static int region_splat_launch(const float* feat, const int32_t* entries, const 
       int dev = 0;                                                                                                \
       (void)hipGetDevice(&dev);                                                                                   \
       if (dev >= 0 && dev < 16 && !big[dev]) {                                                                    \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&region_splat_kernel<CPL, LAY>),                    \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&region_splat_kernel<CPL, LAY, false>),             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024) != hipSuccess ||          \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&region_splat_kernel<CPL, LAY, true>),              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024) != hipSuccess)            \
           return LSS_E_SHAPE;                                                                                     \
         big[dev] = true;                                                                                          \
       }                                                                                                           \
     }                                                                                                             \
-    hipLaunchKernelGGL((region_splat_kernel<CPL, LAY>), grid, dim3(256), lds, st, feat, en, rp, X, Y, Z, bev,     \
-                       stamps, centre_out);                                                                       \
+    if (direct)                                                                                                   \
+      hipLaunchKernelGGL((region_splat_kernel<CPL, LAY, true>), grid, dim3(256), lds, st, feat, en, rp, X, Y, Z, bev, \
+                         stamps, centre_out, da);                                                                 \
+    else                                                                                                          \
+      hipLaunchKernelGGL((region_splat_kernel<CPL, LAY, false>), grid, dim3(256), lds, st, feat, en, rp, X, Y, Z, bev, \
+                         stamps, centre_out, da);                                                                 \
   } while (0)
   if (C == 64) {
     if (layout == LSS_BEV_NCHW_F32) LSS_RS(1, LSS_BEV_NCHW_F32);
@@ -714,7 +829,8 @@ static int lift_splat_forward_impl(const float* frustum, const float* inv_post_r
                                    const float* bx, const float* x, const float* w, const float* bias, int B, int N,
                                    int D, int fH, int fW, int Cin, int C, int X, int Y, int Z, int32_t* voxel,
                                    int32_t* vox_count, int32_t* vox_list, int32_t* entries, int32_t* cursor,
-                                   float* depth, float* feat, void* bev, int layout, int math, void* stream) {
+                                   float* depth, float* feat, void* bev, int layout, int math, void* stream,
+                                   void* direct_entries = nullptr, unsigned long long direct_bytes = 0) {
   int rc;
   // Region-bucketed pipeline (3 launches: K2 || K3 + LDS region histograms, fill, region splat) whenever the
   // depthnet runs in f32 and the problem fits its limits; LSS_SPLAT_LEGACY=1 forces the voxel-list pipeline.
@@ -722,10 +838,14 @@ static int lift_splat_forward_impl(const float* frustum, const float* inv_post_r
   if (math == LSS_DT_F32 && (C == 64 || C == 128) && layout >= 0 && layout <= 2 && vox_count != nullptr &&
       vox_list != nullptr && entries != nullptr && bev != nullptr && B > 0 && N > 0 && D > 0 && fH > 0 && fW > 0 &&
       X > 0 && Y > 0 && Z > 0 && (reinterpret_cast<uintptr_t>(bev) & 15) == 0 &&
-      region_plan_for(B, N, D, fH, fW, C, X, Y, Z, vox_count, vox_list, &rp)) {
+      region_plan_for(B, N, D, fH, fW, C, X, Y, Z, vox_count, vox_list, &rp, direct_entries, direct_bytes)) {
     rc = lss_region_depthnet_voxels(frustum, inv_post_rots, post_trans, combine, trans, calib_host, dx, bx, x, w, bias,
                                     B, N, D, fH, fW, Cin, C, X, Y, Z, voxel, depth, feat, rp, stream);
     if (rc) return rc;
+    if (rp.dentries != nullptr) {  // direct form: launch 1 wrote the entries, no fill launch
+      const DirectArgs da = {depth, voxel, N, D * fH * fW, fH * fW};
+      return region_splat_launch(feat, entries, rp, B, C, X, Y, Z, bev, layout, lss_stream(stream), &da);
+    }
     rc = lss_region_fill(voxel, depth, B, N, D, fH * fW, X, Y, Z, rp, entries, stream);
     if (rc) return rc;
     return region_splat_launch(feat, entries, rp, B, C, X, Y, Z, bev, layout, lss_stream(stream));
@@ -755,12 +875,12 @@ static int lift_splat_forward_impl(const float* frustum, const float* inv_post_r
 
 // Lift-splat of depth / context tensors produced elsewhere (vovnet depth heads, CamEncodeV2): geometry + bucketing +
 // splat behind one call.  Region pipeline when the problem fits it (C = 128 included), else K3 -> K4 -> K5.
-extern "C" int lss_lift_splat_from_heads(const float* frustum, const float* inv_post_rots, const float* post_trans,
-                                         const float* combine, const float* trans, const float* dx, const float* bx,
-                                         const float* depth, const float* feat, int B, int N, int D, int fH, int fW,
-                                         int C, int X, int Y, int Z, int32_t* voxel, int32_t* vox_count,
-                                         int32_t* vox_list, int32_t* entries, int32_t* cursor, void* bev, int layout,
-                                         void* stream) {
+static int lift_splat_from_heads_impl(const float* frustum, const float* inv_post_rots, const float* post_trans,
+                                      const float* combine, const float* trans, const float* dx, const float* bx,
+                                      const float* depth, const float* feat, int B, int N, int D, int fH, int fW,
+                                      int C, int X, int Y, int Z, int32_t* voxel, int32_t* vox_count,
+                                      int32_t* vox_list, int32_t* entries, int32_t* cursor, void* bev, int layout,
+                                      void* stream, void* direct_entries, unsigned long long direct_bytes) {
   LSS_CHECK_PTR(depth); LSS_CHECK_PTR(feat); LSS_CHECK_PTR(voxel); LSS_CHECK_PTR(vox_count); LSS_CHECK_PTR(vox_list);
   LSS_CHECK_PTR(entries); LSS_CHECK_PTR(cursor); LSS_CHECK_PTR(bev);
   LSS_CHECK_POS(B); LSS_CHECK_POS(N); LSS_CHECK_POS(D); LSS_CHECK_POS(fH); LSS_CHECK_POS(fW);
@@ -769,10 +889,15 @@ extern "C" int lss_lift_splat_from_heads(const float* frustum, const float* inv_
   if (layout < 0 || layout > 2) return LSS_E_LAYOUT;
   int rc;
   LssRegionPlan rp;
-  if ((reinterpret_cast<uintptr_t>(bev) & 15) == 0 && region_plan_for(B, N, D, fH, fW, C, X, Y, Z, vox_count, vox_list, &rp)) {
+  if ((reinterpret_cast<uintptr_t>(bev) & 15) == 0 &&
+      region_plan_for(B, N, D, fH, fW, C, X, Y, Z, vox_count, vox_list, &rp, direct_entries, direct_bytes)) {
     rc = lss_region_voxels_absmax(frustum, inv_post_rots, post_trans, combine, trans, dx, bx, feat, B, N, D, fH, fW, C, X,
                                   Y, Z, voxel, rp, stream);
     if (rc) return rc;
+    if (rp.dentries != nullptr) {
+      const DirectArgs da = {depth, voxel, N, D * fH * fW, fH * fW};
+      return region_splat_launch(feat, entries, rp, B, C, X, Y, Z, bev, layout, lss_stream(stream), &da);
+    }
     rc = lss_region_fill(voxel, depth, B, N, D, fH * fW, X, Y, Z, rp, entries, stream);
     if (rc) return rc;
     return region_splat_launch(feat, entries, rp, B, C, X, Y, Z, bev, layout, lss_stream(stream));
@@ -784,6 +909,38 @@ extern "C" int lss_lift_splat_from_heads(const float* frustum, const float* inv_
                          cursor, stream);
   if (rc) return rc;
   return lss_lift_splat_fwd(feat, vox_list, entries, B, N, D, fH, fW, C, X, Y, Z, bev, layout, stream);
+}
+
+extern "C" int lss_lift_splat_from_heads(const float* frustum, const float* inv_post_rots, const float* post_trans,
+                                         const float* combine, const float* trans, const float* dx, const float* bx,
+                                         const float* depth, const float* feat, int B, int N, int D, int fH, int fW,
+                                         int C, int X, int Y, int Z, int32_t* voxel, int32_t* vox_count,
+                                         int32_t* vox_list, int32_t* entries, int32_t* cursor, void* bev, int layout,
+                                         void* stream) {
+  return lift_splat_from_heads_impl(frustum, inv_post_rots, post_trans, combine, trans, dx, bx, depth, feat, B, N, D, fH,
+                                    fW, C, X, Y, Z, voxel, vox_count, vox_list, entries, cursor, bev, layout, stream,
+                                    nullptr, 0);
+}
+
+// Descriptor form of the three entries above / below (lss_lift_splat_forward, _hostcal, _from_heads): the same
+// arguments in one struct, plus the DIRECT entry workspace (lss_lift_splat_direct_bytes) that lets the region pipeline
+// run in two launches instead of three (region_plan.h).  calib_host != NULL: host calibration (the four device
+// calibration pointers are ignored); x == NULL: depth / feat are INPUTS (the _from_heads form).
+extern "C" int lss_lift_splat_forward_desc(const lss_lift_splat_desc_t* d, void* stream) {
+  LSS_CHECK_PTR(d);
+  if (d->x == nullptr) {
+    return lift_splat_from_heads_impl(d->frustum, d->inv_post_rots, d->post_trans, d->combine, d->trans, d->dx, d->bx,
+                                      d->depth, d->feat, d->B, d->N, d->D, d->fH, d->fW, d->C, d->X, d->Y, d->Z, d->voxel,
+                                      d->vox_count, d->vox_list, d->entries, d->cursor, d->bev, d->layout, stream,
+                                      d->direct_entries, d->direct_bytes);
+  }
+  if (d->calib_host != nullptr && d->math != LSS_DT_F32) return LSS_E_LAYOUT;
+  return lift_splat_forward_impl(d->frustum, d->calib_host ? nullptr : d->inv_post_rots,
+                                 d->calib_host ? nullptr : d->post_trans, d->calib_host ? nullptr : d->combine,
+                                 d->calib_host ? nullptr : d->trans, d->calib_host, d->dx, d->bx, d->x, d->w, d->bias, d->B,
+                                 d->N, d->D, d->fH, d->fW, d->Cin, d->C, d->X, d->Y, d->Z, d->voxel, d->vox_count,
+                                 d->vox_list, d->entries, d->cursor, d->depth, d->feat, d->bev, d->layout, d->math, stream,
+                                 d->direct_entries, d->direct_bytes);
 }
 
 extern "C" int lss_lift_splat_forward(const float* frustum, const float* inv_post_rots,

@@ -178,6 +178,49 @@ class SplatWorkspace:
         self.vox_list = torch.empty(nvox, 2, dtype=torch.int32, device=device)
         self.entries = torch.empty(P, 2, dtype=torch.int32, device=device)  # {point id, depth weight}
         self.cursor = torch.zeros(1, dtype=torch.int32, device=device)
+        self._direct = {}
+
+    def direct_buffer(self, dims, nx):
+        """The larger entry workspace of the two-launch (direct) region pipeline (lss_lift_splat_direct_bytes): fixed-
+        capacity per-region buckets, 8 KiB per region (20 MB at batch 4, 200 x 200); None where the region pipeline
+        does not apply or with LSS_SPLAT_DIRECT=0.  Allocated on first use (a warm-up step, never inside a capture)."""
+        key = (tuple(dims), tuple(nx))
+        if key not in self._direct:
+            B, Ncam, D, fH, fW, C = dims
+            X, Y, Z = nx
+            n = 0 if os.environ.get("LSS_SPLAT_DIRECT") == "0" else \
+                int(N.lib().lss_lift_splat_direct_bytes(B, Ncam, D, fH, fW, C, X, Y, Z))
+            self._direct[key] = torch.empty(n, dtype=torch.uint8, device=self.voxel.device) if n else None
+        return self._direct[key]
+
+
+def _lift_splat_desc(ws, dims, nx, layout, math, bev, depth, feat, frustum, dx, bx, x=None, w=None, bias=None, Cin=0,
+                     calib_dev=None, calib_host=None):
+    """One lss_lift_splat_desc_t for the three forms of the fused lift-splat call (include/lss_hip.h)."""
+    B, Ncam, D, fH, fW, C = dims
+    X, Y, Z = nx
+    d = N.LiftSplatDesc()
+    P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    d.frustum, d.dx, d.bx = P(frustum), P(dx), P(bx)
+    if calib_host is not None:
+        d.calib_host = calib_host.data_ptr()
+    else:
+        d.inv_post_rots, d.post_trans, d.combine, d.trans = (P(t) for t in calib_dev)
+    d.x, d.w, d.bias = P(x), P(w), P(bias)
+    d.voxel, d.vox_count, d.vox_list = P(ws.voxel), P(ws.vox_count), P(ws.vox_list)
+    d.entries, d.cursor = P(ws.entries), P(ws.cursor)
+    direct = ws.direct_buffer(dims, nx)
+    d.direct_entries = P(direct)
+    d.direct_bytes = 0 if direct is None else direct.numel()
+    d.depth, d.feat, d.bev = P(depth), P(feat), P(bev)
+    d.B, d.N, d.D, d.fH, d.fW, d.Cin, d.C, d.X, d.Y, d.Z = B, Ncam, D, fH, fW, Cin, C, X, Y, Z
+    d.layout, d.math = layout, math
+    return d
+
+
+def _run_desc(d, what):
+    import ctypes
+    N.check(N.lib().lss_lift_splat_forward_desc(ctypes.byref(d), N.stream()), what)
 
 
 def points_to_voxels(frustum, inv_post_rots, post_trans, combine, trans, dx, bx, nx, ws,
@@ -358,11 +401,8 @@ def lift_splat_forward(frustum, inv_post_rots, post_trans, combine, trans, dx, b
     else:
         bev = torch.empty(B, X, Y, Z * C, dtype=torch.float32 if layout == BEV_NHWC_F32 else torch.bfloat16, device=dev)
         out = bev.permute(0, 3, 1, 2)
-    N.check(N.lib().lss_lift_splat_forward(
-        N.ptr(frustum), N.ptr(inv_post_rots), N.ptr(post_trans), N.ptr(combine), N.ptr(trans), N.ptr(dx), N.ptr(bx),
-        N.ptr(x), N.ptr(w2), N.ptr(bias), B, Ncam, D, fH, fW, Cin, C, X, Y, Z, N.ptr(ws.voxel), N.ptr(ws.vox_count),
-        N.ptr(ws.vox_list), N.ptr(ws.entries), N.ptr(ws.cursor), N.ptr(depth), N.ptr(feat), N.ptr(bev), layout, math,
-        N.stream()), "lss_lift_splat_forward")
+    _run_desc(_lift_splat_desc(ws, dims, nx, layout, math, bev, depth, feat, frustum, dx, bx, x, w2, bias, Cin,
+                               calib_dev=(inv_post_rots, post_trans, combine, trans)), "lss_lift_splat_forward_desc")
     return out, depth, feat
 
 
@@ -454,11 +494,9 @@ def lift_splat_from_heads(frustum, inv_post_rots, post_trans, combine, trans, dx
     else:
         bev = torch.empty(B, X, Y, Z * C, dtype=torch.float32 if layout == BEV_NHWC_F32 else torch.bfloat16, device=dev)
         out = bev.permute(0, 3, 1, 2)
-    N.check(N.lib().lss_lift_splat_from_heads(
-        N.ptr(frustum), N.ptr(inv_post_rots), N.ptr(post_trans), N.ptr(combine), N.ptr(trans), N.ptr(dx), N.ptr(bx),
-        N.ptr(depth), N.ptr(feat), B, Ncam, D, fH, fW, C, X, Y, Z, N.ptr(ws.voxel), N.ptr(ws.vox_count),
-        N.ptr(ws.vox_list), N.ptr(ws.entries), N.ptr(ws.cursor), N.ptr(bev), layout, N.stream()),
-        "lss_lift_splat_from_heads")
+    _run_desc(_lift_splat_desc(ws, dims, nx, layout, DT_F32, bev, depth, feat, frustum, dx, bx,
+                               calib_dev=(inv_post_rots, post_trans, combine, trans)),
+              "lss_lift_splat_forward_desc (from heads)")
     return out
 
 
@@ -489,10 +527,8 @@ def lift_splat_forward_hostcal(frustum, calib_host, dx, bx, x, weight, bias, ws,
     else:
         bev = torch.empty(B, X, Y, Z * C, dtype=torch.float32 if layout == BEV_NHWC_F32 else torch.bfloat16, device=dev)
         out = bev.permute(0, 3, 1, 2)
-    N.check(N.lib().lss_lift_splat_forward_hostcal(
-        N.ptr(frustum), calib_host.data_ptr(), N.ptr(dx), N.ptr(bx), N.ptr(x), N.ptr(w2), N.ptr(bias), B, Ncam, D, fH, fW,
-        Cin, C, X, Y, Z, N.ptr(ws.voxel), N.ptr(ws.vox_count), N.ptr(ws.vox_list), N.ptr(ws.entries), N.ptr(ws.cursor),
-        N.ptr(depth), N.ptr(feat), N.ptr(bev), layout, N.stream()), "lss_lift_splat_forward_hostcal")
+    _run_desc(_lift_splat_desc(ws, dims, nx, layout, DT_F32, bev, depth, feat, frustum, dx, bx, x, w2, bias, Cin,
+                               calib_host=calib_host), "lss_lift_splat_forward_desc (host calibration)")
     return out, depth, feat
 
 

@@ -224,3 +224,35 @@ def test_region_pipeline_all_points_dropped(ops, monkeypatch):
         bev, _, _, ws = run(ops, pr, layout, False, monkeypatch)
         assert float(bev.float().abs().sum()) == 0.0 and int((ws.voxel >= 0).sum()) == 0
         assert int(ws.vox_count.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("layout", [0, 2])
+def test_direct_form_equals_three_launch_form_bit_for_bit(ops, monkeypatch, case, layout):
+    """The two-launch (direct) region pipeline - the geometry workgroups write their points into fixed-capacity
+    per-region buckets, no fill launch, the splat gathers the depth weights - against the three-launch form on the
+    same operands: the sums are exact fixed-point integers, so the grids must be EQUAL, bit for bit, whatever order the
+    two bucketings produced; the zero-between-calls words are back at zero; and a second call on the same workspace
+    reproduces the first.  CASES[3] (about 900 points in its busiest regions) and CASES[4] (one region holding every
+    point of the sample: far beyond the 1024 slots of its bucket) take the overflow path, which rebuilds such a region
+    from the voxel ids (ref src/model_BEV_TXT.py:84-126: the sums are the same whichever way the points are grouped)."""
+    B, N, D, fH, fW, C, grid, fd, rc = CASES[case]
+    pr = problem(B, N, D, fH, fW, C, grid, fd, seed=case, randn_calib=rc)
+    X, Y, Z = pr["nx"]
+    assert ops.N.lib().lss_lift_splat_direct_bytes(B, N, D, fH, fW, C, X, Y, Z) > 0
+    monkeypatch.setenv("LSS_SPLAT_DIRECT", "0")
+    ref, depth0, feat0, ws0 = run(ops, pr, layout, False, monkeypatch)
+    assert ws0.direct_buffer(pr["dims"], (X, Y, Z)) is None
+    monkeypatch.delenv("LSS_SPLAT_DIRECT")
+    bev, depth, feat, ws = run(ops, pr, layout, False, monkeypatch)
+    assert ws.direct_buffer(pr["dims"], (X, Y, Z)) is not None   # the direct workspace was handed over
+    assert torch.equal(ws.voxel, ws0.voxel) and torch.equal(depth, depth0) and torch.equal(feat, feat0)
+    assert torch.equal(bev, ref)
+    assert int(ws.vox_count.abs().sum()) == 0 and int(ws.cursor.abs().sum()) == 0
+    bev2, *_ = run(ops, pr, layout, False, monkeypatch, ws=ws)
+    assert torch.equal(bev2, ref)
+    if case == 4:  # really the overflow path: more points in the one region than a bucket holds
+        assert int((ws.voxel >= 0).sum()) > 1024
+    # the host-calibration entry takes the direct form too
+    bev_h, *_ = run(ops, pr, layout, False, monkeypatch, hostcal=True)
+    assert torch.equal(bev_h, ref)
