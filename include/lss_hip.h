@@ -63,6 +63,10 @@ extern "C" {
  * lss_conv2d_pack_weights_ring and the launch runs on the loader / consumer ring kernel (csrc/conv_ring.hip);
  * LSS_E_SHAPE when lss_conv2d_ring_ok() says the shape is not one of its cases. */
 #define LSS_W_RING 64
+/* lss_conv2d_fwd (3x3, stride 1, pad 1, bf16, no skip tensor): `w_packed` is in the layout of lss_conv2d_pack_weights_ks
+ * and the launch runs on the K-split one-pass kernel of the launch-bound layers (csrc/conv_ks.hip); LSS_E_SHAPE when
+ * lss_conv2d_ks_ok() says the shape is not one of its cases. */
+#define LSS_W_KS 128
 /* lss_conv2d_fwd, 1x1 bf16 only: y is written head-major, (B, Cout/32, Ho*Wo, 32), the
  * layout the deformable-attention gather reads with the fewest cache lines */
 #define LSS_OUT_HEAD_MAJOR32 32
@@ -290,6 +294,16 @@ int lss_conv2d_pack_weights_ring(const float* w_oihw, int Cout, int Cin, void* w
 int lss_conv2d_pack_weights_ring_dgrad(const float* w_oihw, int Cout, int Cin, void* w_packed, void* stream);
 /* flag waits of the ring kernel that hit their bound since load (must be 0; synchronises the device) */
 int lss_conv2d_ring_timeouts(void);
+
+/* K8k  the launch-bound 3x3 / stride-1 convs of resnet18's layer1-3 inside BevEncode (replaces the conv + BN + ReLU
+ * (+ identity) of torchvision's BasicBlock as called from src/modules.py:104-106, 123-125) as ONE pass per workgroup:
+ * the whole input patch of a pixel block in LDS, the K dimension split over the waves, the weights in registers.
+ * lss_conv2d_ks_ok: 1 when (B, H, W, Cin, Cout) is a case for it (Cin in {64, 128, 256}, Cout % 32 == 0, 64-512
+ * workgroups).  Weight layout: [32-channel output block][k-step = 32 input channels of one tap][2 channel tiles][lane][8]
+ * bf16 - each wave's A fragments as they lie in its registers; use with lss_conv2d_fwd(..., relu | LSS_W_KS). */
+int lss_conv2d_ks_ok(int B, int H, int W, int Cin, int Cout);
+size_t lss_conv2d_ks_packed_weight_bytes(int Cout, int Cin);
+int lss_conv2d_pack_weights_ks(const float* w_oihw, int Cout, int Cin, void* w_packed, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K8b  gradients of the convolutions (training; replaces the ConvolutionBackward autograd

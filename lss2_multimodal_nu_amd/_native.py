@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("LSS_HIP_LIB") or os.path.join(_HERE, "csrc", "liblss_
 
 BEV_NCHW_F32, BEV_NHWC_F32, BEV_NHWC_BF16 = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_GELU, OUT_F32, OUT_HEAD_MAJOR32, W_RING = 0, 1, 2, 16, 32, 64
+ACT_NONE, ACT_RELU, ACT_GELU, OUT_F32, OUT_HEAD_MAJOR32, W_RING, W_KS = 0, 1, 2, 16, 32, 64, 128
 VALUE_NHWC, VALUE_HEAD_MAJOR = 0, 1
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
@@ -48,6 +48,9 @@ SIGNATURES = {
     "lss_conv2d_ring_packed_weight_bytes": (_sz, [_i, _i]),
     "lss_conv2d_pack_weights_ring": (_i, [_vp, _i, _i, _vp, _vp]),
     "lss_conv2d_pack_weights_ring_dgrad": (_i, [_vp, _i, _i, _vp, _vp]),
+    "lss_conv2d_ks_ok": (_i, [_i] * 5),
+    "lss_conv2d_ks_packed_weight_bytes": (_sz, [_i, _i]),
+    "lss_conv2d_pack_weights_ks": (_i, [_vp, _i, _i, _vp, _vp]),
     "lss_conv2d_wgrad_timeouts": (_i, []),
     "lss_conv2d_ring_timeouts": (_i, []),
     "lss_conv2d_pack_weights_dgrad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

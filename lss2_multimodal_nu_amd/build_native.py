@@ -24,6 +24,7 @@ SOURCES = {
     "splat.hip": [],
     "conv_mfma.hip": [],
     "conv_ring.hip": ["-fno-slp-vectorize"],  # no v_pk_*_f32 next to MFMAs (MI355X_MICROARCH.md)
+    "conv_ks.hip": [],
     "layout.hip": [],
     "bev_transformer.hip": [],
     "linear_mfma.hip": [],

@@ -28,6 +28,9 @@ int lss_conv_ring_launch(const void* x, const void* x2, const void* w_ring, cons
                          void* y, const float* head_w, const float* head_b, float* head_out, int head_n, int B, int H,
                          int W, int Cx, int C2, int up, int Cout, int relu, int wt, hipStream_t st);  // conv_ring.hip
 
+int lss_conv_ks_launch(const void* x, const void* w_ks, const float* scale, const float* shift, const void* residual,
+                       void* y, int B, int H, int W, int Cin, int Cout, int relu, int wt, hipStream_t st);  // conv_ks.hip
+
 namespace {
 
 struct ConvArgs {
@@ -1233,6 +1236,14 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
   if (pad < 0 || C2 < 0) return LSS_E_SHAPE;
   if (dt != LSS_DT_F32 && dt != LSS_DT_BF16) return LSS_E_LAYOUT;
   if (C2 > 0 && x2 == nullptr) return LSS_E_NULL;
+  if (relu & LSS_W_KS) {  // KS-packed weights: the K-split one-pass kernel of the launch-bound layers, or nothing
+    if (dt != LSS_DT_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || stats != nullptr || C2 != 0 || up != 1 ||
+        (relu & ~(LSS_W_KS | 1)) != 0)
+      return LSS_E_SHAPE;
+    const bool wt_ks = (getenv("LSS_CONV_WT") == nullptr || atoi(getenv("LSS_CONV_WT")) != 0);
+    return lss_conv_ks_launch(x, w_packed, scale, shift, residual, y, B, H, W, Cx, Cout, relu & 1, wt_ks ? 1 : 0,
+                              lss_stream(stream));
+  }
   if (relu & LSS_W_RING) {  // ring-packed weights: the loader / consumer kernel, or nothing
     if (dt != LSS_DT_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || residual != nullptr || stats != nullptr ||
         (relu & ~(LSS_W_RING | 1)) != 0)

@@ -532,6 +532,26 @@ class _FoldedConv:
         self.key = None
         self.w = self.scale = self.shift = None
         self.w_ring, self.ring_key = None, None
+        self.w_ks, self.ks_key = None, None
+
+    def ks(self, dt):
+        """The same weights in the K-split one-pass kernel's layout (csrc/conv_ks.hip), packed on first use and
+        whenever a source tensor changes; `get(dt)` must have been called for the current key."""
+        if self.ks_key != self.key:
+            with torch.no_grad():
+                self.w_ks = ops.pack_conv_weight_ks(self.conv.weight.detach().float().contiguous())
+            self.ks_key = self.key
+        return self.w_ks
+
+    def ks_case(self, x, dt, x2=None, up=1):
+        """Does this call go to the K-split one-pass kernel?  3x3 / stride 1 / pad 1, bf16, no fused gather, and a shape
+        `lss_conv2d_ks_ok` accepts (layer1-3 of BevEncode at the benchmark sizes)."""
+        c = self.conv
+        if (dt != ops.DT_BF16 or x2 is not None or up != 1 or c.kernel_size != (3, 3) or c.stride != (1, 1)
+                or c.padding != (1, 1) or not self.pack or self.pad_in is not None):
+            return False
+        B, H, W, Cx = x.shape
+        return ops.conv_ks_ok(B, H, W, Cx, c.out_channels)
 
     def ring(self, dt):
         """The same weights in the ring kernel's layout (csrc/conv_ring.hip), packed on first use and whenever a
@@ -609,7 +629,9 @@ class _FoldedConv:
         c = self.conv
         if self._s2d(dt) and x2 is None and up == 1:
             return ops.conv2d_s2_nhwc(x, w, c.kernel_size[0], c.padding[0], scale, shift, residual, relu)
-        if relu in (False, True) and self.ring_case(x, dt, residual, x2, up):
+        if relu in (False, True) and self.ks_case(x, dt, x2, up):
+            w = self.ks(dt)
+        elif relu in (False, True) and self.ring_case(x, dt, residual, x2, up):
             w = self.ring(dt)
         return ops.conv2d_nhwc(x, w, c.kernel_size, c.stride[0], c.padding[0], scale, shift, residual, relu,
                                x2=x2, up=up, dt=dt)

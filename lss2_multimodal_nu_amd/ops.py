@@ -10,7 +10,7 @@ import torch
 
 from . import _native as N
 from ._native import (ACT_GELU, ACT_NONE, ACT_RELU, BEV_NCHW_F32, BEV_NHWC_BF16, BEV_NHWC_F32, DT_BF16,  # noqa: F401
-                      DT_F32, OUT_F32, OUT_HEAD_MAJOR32, VALUE_HEAD_MAJOR, VALUE_NHWC, W_RING)
+                      DT_F32, OUT_F32, OUT_HEAD_MAJOR32, VALUE_HEAD_MAJOR, VALUE_NHWC, W_KS, W_RING)
 
 
 def _f32c(t, name, shape=None):
@@ -646,6 +646,28 @@ class RingWeight:
         self.data, self.Cout, self.Cin = data, Cout, Cin
 
 
+class KsWeight(RingWeight):
+    """3x3 weights in the layout of the K-split one-pass kernel (csrc/conv_ks.hip)."""
+
+
+def conv_ks_ok(B, H, W, Cin, Cout):
+    """Is this 3x3 / stride-1 / pad-1 bf16 conv a case for the K-split one-pass kernel (lss_conv2d_ks_ok)?"""
+    return bool(N.lib().lss_conv2d_ks_ok(B, H, W, Cin, Cout))
+
+
+def pack_conv_weight_ks(w_oihw):
+    """OIHW fp32 (3x3) -> KsWeight."""
+    Cout, Cin, KH, KW = w_oihw.shape
+    _f32c(w_oihw, "conv weight")
+    nbytes = N.lib().lss_conv2d_ks_packed_weight_bytes(Cout, Cin)
+    if (KH, KW) != (3, 3) or nbytes == 0:
+        raise ValueError("KS weights: 3x3, Cout %% 32 == 0, Cin in (64, 128, 256) (got %s)" % (tuple(w_oihw.shape),))
+    out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w_oihw.device)
+    N.check(N.lib().lss_conv2d_pack_weights_ks(N.ptr(w_oihw), Cout, Cin, N.ptr(out), N.stream()),
+            "lss_conv2d_pack_weights_ks")
+    return KsWeight(out, Cout, Cin)
+
+
 def conv_ring_ok(B, H, W, Cx, C2, up, Cout, head_n=0):
     """Is this 3x3 / stride-1 / pad-1 bf16 conv a case for the ring kernel (lss_conv2d_ring_ok)?"""
     if os.environ.get("LSS_CONV_RING") == "0":
@@ -689,8 +711,8 @@ def conv2d_nhwc(x, w_packed, ksize, stride, pad, scale=None, shift=None, residua
     act = int(relu) | (OUT_F32 if (out_f32 and dt == DT_BF16) else 0) | (OUT_HEAD_MAJOR32 if head_major else 0)
     B, H, W, Cx = x.shape
     KH, KW = ksize
-    if isinstance(w_packed, RingWeight):  # the ring kernel's layout (3x3 / s1 / p1 bf16 only; the C side checks)
-        act |= W_RING
+    if isinstance(w_packed, RingWeight):  # the ring / KS kernels' layouts (3x3 / s1 / p1 bf16 only; the C side checks)
+        act |= W_KS if isinstance(w_packed, KsWeight) else W_RING
         taps, Cout, Cin, w_packed = 9, w_packed.Cout, w_packed.Cin, w_packed.data
     else:
         taps, Cout, Cin = w_packed.shape

@@ -9,6 +9,11 @@ python -m lss2_multimodal_nu_amd.build_native > /dev/null
 cd "$(dirname "$0")/../lss2_multimodal_nu_amd/csrc"
 mkdir -p ../../diag_libs /tmp/lss_diag
 for v in STATS NOBLEND NOWDMA "$@"; do
+  case "$v" in KS_*)   # timing-only builds of the K-split kernel: KS_NOREAD (fragments read once), KS_NOMFMA (reads only)
+    /opt/rocm/bin/hipcc -c conv_ks.hip -o /tmp/lss_diag/conv_ks_$v.o -O3 -fPIC -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -I../../include -DKS_DIAG_${v:3}
+    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../diag_libs/liblss_$v.so $(ls build/*.o | grep -v conv_ks.o) /tmp/lss_diag/conv_ks_$v.o -ldl
+    continue;;
+  esac
   def=-DRK_DIAG_$v; [ "$v" = STATS ] && def=-DRK_STATS
   case "$v" in PSLEEP*) def="-DRK_PSLEEP=${v:6}";; esac
   case "$v" in PRIO*) def="-DRK_PRIO_C=${v:4:1} -DRK_PRIO_P=${v:5:1} -DRK_PRIO_W=${v:6:1}";; esac
