@@ -7,6 +7,8 @@ them; the sums run in the HIP segmented-sum kernel (direct per-run sums, not a
 cumsum followed by differences - ~1000x less rounding noise).
 The fused `LSS.forward` path does not go through them at all.
 """
+import os
+
 import torch
 
 from . import ops
@@ -154,8 +156,9 @@ class _Head1x1Fn(torch.autograd.Function):
 
 def head_1x1(y, head):
     """head(y) on the autograd path: the HIP head kernels when the shapes fit (128 input channels, 4 or 8 classes, a
-    bf16 activation on the GPU), torch's convolution otherwise (fp32 parity mode; NOT safe inside a HIP graph)."""
-    if (y.is_cuda and y.dtype == torch.bfloat16 and y.dim() == 4 and y.shape[1] == 128 and head.kernel_size == (1, 1)
+    bf16 activation on the GPU), torch's convolution otherwise (fp32 parity mode, or LSS_TRAIN_NATIVE=0 - the
+    library comparison leg of the tests; NOT safe inside a HIP graph)."""
+    if (os.environ.get("LSS_TRAIN_NATIVE", "1") != "0" and y.is_cuda and y.dtype == torch.bfloat16 and y.dim() == 4 and y.shape[1] == 128 and head.kernel_size == (1, 1)
             and head.stride == (1, 1) and head.bias is not None and head.out_channels in (4, 8)):
         return _Head1x1Fn.apply(y, head.weight, head.bias)
     return head(y)
