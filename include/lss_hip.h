@@ -304,6 +304,10 @@ int lss_conv2d_ring_timeouts(void);
 int lss_conv2d_ks_ok(int B, int H, int W, int Cin, int Cout);
 size_t lss_conv2d_ks_packed_weight_bytes(int Cout, int Cin);
 int lss_conv2d_pack_weights_ks(const float* w_oihw, int Cout, int Cin, void* w_packed, void* stream);
+/* the same image for the INPUT-GRADIENT conv of that layer (training): w_oihw is the forward layer's (Cout, Cin, 3, 3);
+ * the gradient conv maps Cout -> Cin channels with transposed, tap-flipped weights (needs Cout in {64, 128, 256},
+ * Cin % 32 == 0) */
+int lss_conv2d_pack_weights_ks_dgrad(const float* w_oihw, int Cout, int Cin, void* w_packed, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K8b  gradients of the convolutions (training; replaces the ConvolutionBackward autograd

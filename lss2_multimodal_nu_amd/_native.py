@@ -51,6 +51,7 @@ SIGNATURES = {
     "lss_conv2d_ks_ok": (_i, [_i] * 5),
     "lss_conv2d_ks_packed_weight_bytes": (_sz, [_i, _i]),
     "lss_conv2d_pack_weights_ks": (_i, [_vp, _i, _i, _vp, _vp]),
+    "lss_conv2d_pack_weights_ks_dgrad": (_i, [_vp, _i, _i, _vp, _vp]),
     "lss_conv2d_wgrad_timeouts": (_i, []),
     "lss_conv2d_ring_timeouts": (_i, []),
     "lss_conv2d_pack_weights_dgrad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

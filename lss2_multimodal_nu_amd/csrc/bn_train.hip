@@ -312,11 +312,14 @@ extern "C" int lss_conv_bn_act_train_fwd(const void* x1, const void* x2, const f
                                          int up, int Cout, float momentum, float eps, int relu, void* stream) {
   // the big layers run on the loader / consumer ring kernel (conv_ring.hip), like the inference path
   const bool ring = train_ring_enabled() && lss_conv2d_ring_ok(B, H, W, Cx, C2, up, Cout, 0);
+  // ... and the launch-bound ones (layer1-3) on the K-split one-pass kernel (conv_ks.hip)
+  const bool ks = !ring && C2 == 0 && up == 1 && lss_conv2d_ks_ok(B, H, W, Cx, Cout);
   int rc = ring ? lss_conv2d_pack_weights_ring(w_oihw, Cout, Cx + C2, w_packed, stream)
+           : ks ? lss_conv2d_pack_weights_ks(w_oihw, Cout, Cx, w_packed, stream)
                 : lss_conv2d_pack_weights(w_oihw, Cout, Cx + C2, 3, 3, LSS_DT_BF16, w_packed, stream);
   if (rc != 0) return rc;
   rc = lss_conv2d_fwd(x1, x2, w_packed, nullptr, nullptr, nullptr, z, nullptr, B, H, W, Cx, C2, up, Cout, 3, 3, 1, 1,
-                      LSS_ACT_NONE | (ring ? LSS_W_RING : 0), LSS_DT_BF16, stream);
+                      LSS_ACT_NONE | (ring ? LSS_W_RING : 0) | (ks ? LSS_W_KS : 0), LSS_DT_BF16, stream);
   if (rc != 0) return rc;
   const long long M = (long long)B * (H * up) * (W * up);
   return lss_bn_train_fwd(z, residual, M, Cout, gamma, beta, running_mean, running_var, momentum, eps, relu,
@@ -338,11 +341,13 @@ extern "C" int lss_conv_bn_act_train_bwd(const void* dy, const void* y, const vo
   if (gcat != nullptr) {  // input gradient(s): dgrad conv over the (concatenated, upsampled) input
     LSS_CHECK_PTR(w_dgrad);
     const bool ring = train_ring_enabled() && lss_conv2d_ring_ok(B, Hh, Wh, Cout, 0, 1, Ct, 0);
+    const bool ks = !ring && lss_conv2d_ks_ok(B, Hh, Wh, Cout, Ct);
     rc = ring ? lss_conv2d_pack_weights_ring_dgrad(w_oihw, Cout, Ct, w_dgrad, stream)
+         : ks ? lss_conv2d_pack_weights_ks_dgrad(w_oihw, Cout, Ct, w_dgrad, stream)
               : lss_conv2d_pack_weights_dgrad(w_oihw, Cout, Ct, 3, 3, LSS_DT_BF16, w_dgrad, stream);
     if (rc != 0) return rc;
     rc = lss_conv2d_fwd(dz, nullptr, w_dgrad, nullptr, nullptr, nullptr, gcat, nullptr, B, Hh, Wh, Cout, 0, 1, Ct, 3, 3,
-                        1, 1, LSS_ACT_NONE | (ring ? LSS_W_RING : 0), LSS_DT_BF16, stream);
+                        1, 1, LSS_ACT_NONE | (ring ? LSS_W_RING : 0) | (ks ? LSS_W_KS : 0), LSS_DT_BF16, stream);
     if (rc != 0) return rc;
     if (g1 != nullptr) {
       rc = lss_upsample_bwd_nhwc(gcat, B, H, W, Cx, Ct, C2, up, g1, stream);

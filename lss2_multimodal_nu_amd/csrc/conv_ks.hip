@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256, 1) void conv_ks_kernel(const KsArgs a) {
     if (a.stamps != nullptr && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime();
   };
   stamp(0);
+  unsigned long long clk_main = 0;  // shader-clock cycles of the main phase (slot 7 of the stamps)
 
   // ---- which block: XCD-aware order, channel blocks of one pixel block adjacent (they share the input patch) ----
   int t;
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(256, 1) void conv_ks_kernel(const KsArgs a) {
 #pragma unroll
     for (int j = 0; j < PXT; ++j) fb[buf][j] = *reinterpret_cast<const bf16x8*>(cbase + ab[j] + toff);
   };
+  if (a.stamps != nullptr) clk_main = __builtin_amdgcn_s_memtime();
   load_frags(0, 0);
 #pragma unroll
   for (int s = 0; s < KSW; ++s) {
@@ -217,6 +219,7 @@ __global__ __launch_bounds__(256, 1) void conv_ks_kernel(const KsArgs a) {
   // ---- the K parts meet: part[kp][tile][ct][lane] (16 B each), summed in the fixed order kp = 0 .. NKW - 1 ----
   if (a.stamps != nullptr) asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[PXT - 1][1]));  // the MFMA chain has retired
   stamp(3);
+  if (a.stamps != nullptr && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - clk_main;
   __syncthreads();  // every wave is done reading the patch: its LDS is free
   f32x4* part = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
@@ -286,7 +289,10 @@ __global__ __launch_bounds__(256, 1) void conv_ks_kernel(const KsArgs a) {
 // OIHW fp32 -> the kernel's register image, bf16: [co block of 32][K part][k-step][channel tile][lane][8], where k-step
 // S = kp * KSW + s covers chunk S / 9 (32 input channels) of tap S % 9, A-fragment lane (kq = lane >> 4, m = lane & 15)
 // holds W[co = cb * 32 + 8 (m >> 2) + 4 ct + (m & 3)][ci = 32 chunk + 8 kq .. + 8][tap]
-__global__ void pack_weights_ks_kernel(const float* __restrict__ w, int Cout, int Cin, unsigned short* __restrict__ out) {
+// dgrad = 1: the image of the TRANSPOSED, tap-flipped weights (the input-gradient conv: Cout x Cin here are the
+// gradient conv's own output / input channels, w is the forward layer's (Cin, Cout, 3, 3))
+__global__ void pack_weights_ks_kernel(const float* __restrict__ w, int Cout, int Cin, unsigned short* __restrict__ out,
+                                       int dgrad) {
   const size_t ntot = (size_t)Cout * Cin * 9;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < ntot; e += (size_t)gridDim.x * 256) {
     const int j = e & 7;
@@ -299,7 +305,7 @@ __global__ void pack_weights_ks_kernel(const float* __restrict__ w, int Cout, in
     const int m = l & 15, kq = l >> 4;
     const int co = cb * 32 + 8 * (m >> 2) + 4 * ct + (m & 3);
     const int ci = (S / 9) * 32 + kq * 8 + j;
-    out[e] = lss_f2bf(w[((size_t)co * Cin + ci) * 9 + (S % 9)]);
+    out[e] = lss_f2bf(dgrad ? w[((size_t)ci * Cout + co) * 9 + (8 - S % 9)] : w[((size_t)co * Cin + ci) * 9 + (S % 9)]);
   }
 }
 
@@ -370,7 +376,19 @@ extern "C" int lss_conv2d_pack_weights_ks(const float* w_oihw, int Cout, int Cin
   const size_t n = (size_t)Cout * Cin * 9;
   const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
   hipLaunchKernelGGL(pack_weights_ks_kernel, dim3(grid), dim3(256), 0, lss_stream(stream), w_oihw, Cout, Cin,
-                     reinterpret_cast<unsigned short*>(w_packed));
+                     reinterpret_cast<unsigned short*>(w_packed), 0);
+  return lss_launch_status();
+}
+
+// weights of the input-gradient conv of a 3x3 / stride-1 layer, K-split image: w_oihw is the FORWARD layer's
+// (Cout, Cin, 3, 3); the gradient conv maps Cout -> Cin channels with the taps flipped
+extern "C" int lss_conv2d_pack_weights_ks_dgrad(const float* w_oihw, int Cout, int Cin, void* w_packed, void* stream) {
+  LSS_CHECK_PTR(w_oihw); LSS_CHECK_PTR(w_packed);
+  if (lss_conv2d_ks_packed_weight_bytes(Cin, Cout) == 0) return LSS_E_SHAPE;
+  const size_t n = (size_t)Cout * Cin * 9;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(pack_weights_ks_kernel, dim3(grid), dim3(256), 0, lss_stream(stream), w_oihw, Cin, Cout,
+                     reinterpret_cast<unsigned short*>(w_packed), 1);
   return lss_launch_status();
 }
 

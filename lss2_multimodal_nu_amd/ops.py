@@ -655,17 +655,20 @@ def conv_ks_ok(B, H, W, Cin, Cout):
     return bool(N.lib().lss_conv2d_ks_ok(B, H, W, Cin, Cout))
 
 
-def pack_conv_weight_ks(w_oihw):
-    """OIHW fp32 (3x3) -> KsWeight."""
+def pack_conv_weight_ks(w_oihw, dgrad=False):
+    """OIHW fp32 (3x3) -> KsWeight; dgrad=True: the weights of the layer's input-gradient conv (Cout -> Cin channels,
+    transposed and tap-flipped), as the training units pack them."""
     Cout, Cin, KH, KW = w_oihw.shape
     _f32c(w_oihw, "conv weight")
-    nbytes = N.lib().lss_conv2d_ks_packed_weight_bytes(Cout, Cin)
+    co, ci = (Cin, Cout) if dgrad else (Cout, Cin)   # channels of the conv the image is for
+    nbytes = N.lib().lss_conv2d_ks_packed_weight_bytes(co, ci)
     if (KH, KW) != (3, 3) or nbytes == 0:
-        raise ValueError("KS weights: 3x3, Cout %% 32 == 0, Cin in (64, 128, 256) (got %s)" % (tuple(w_oihw.shape),))
+        raise ValueError("KS weights: 3x3, Cout %% 32 == 0, Cin in (64, 128, 256) (got %s%s)"
+                         % (tuple(w_oihw.shape), ", dgrad" if dgrad else ""))
     out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w_oihw.device)
-    N.check(N.lib().lss_conv2d_pack_weights_ks(N.ptr(w_oihw), Cout, Cin, N.ptr(out), N.stream()),
-            "lss_conv2d_pack_weights_ks")
-    return KsWeight(out, Cout, Cin)
+    fn = N.lib().lss_conv2d_pack_weights_ks_dgrad if dgrad else N.lib().lss_conv2d_pack_weights_ks
+    N.check(fn(N.ptr(w_oihw), Cout, Cin, N.ptr(out), N.stream()), "lss_conv2d_pack_weights_ks")
+    return KsWeight(out, co, ci)
 
 
 def conv_ring_ok(B, H, W, Cx, C2, up, Cout, head_n=0):

@@ -85,3 +85,24 @@ def test_ks_weights_are_rejected_where_the_kernel_has_no_case(ops):
     assert not ops.conv_ks_ok(4, 400, 400, 64, 64)                  # 2000 workgroups: the tile kernel's territory
     assert not ops.conv_ks_ok(4, 100, 60, 64, 64)                   # a 320-pixel block would span six rows of 60
     assert not ops.conv_ks_ok(4, 40, 40, 256, 256)                  # 7 x 42 positions x 256 channels: more than the patch LDS
+
+
+@pytest.mark.parametrize("cfg", [(4, 25, 25, 256, 256), (4, 50, 50, 128, 128), (3, 50, 44, 64, 128), (4, 100, 100, 64, 64)])
+def test_ks_input_gradient_conv_vs_autograd(ops, report, cfg):
+    """The dgrad image of the weights (lss_conv2d_pack_weights_ks_dgrad: transposed, taps flipped) run through the same
+    kernel = d/dx of conv2d(x, w, padding=1), against torch's CPU autograd on bf16-rounded operands."""
+    B, H, W, Cin, Cout = cfg
+    assert ops.conv_ks_ok(B, H, W, Cout, Cin), "the gradient conv (Cout -> Cin) must be a case for the kernel"
+    gen = torch.Generator().manual_seed(sum(cfg))
+    w = _q(torch.randn(Cout, Cin, 3, 3, generator=gen) * (Cin * 9) ** -0.5)
+    dz = _q(torch.randn(B, Cout, H, W, generator=gen))
+    x = torch.zeros(B, Cin, H, W, requires_grad=True)
+    torch.nn.functional.conv2d(x, w, None, padding=1).backward(dz)
+    ref = x.grad
+    wd = ops.pack_conv_weight_ks(w.cuda(), dgrad=True)
+    assert (wd.Cout, wd.Cin) == (Cin, Cout)
+    dx = ops.conv2d_nhwc(ops.nchw_to_nhwc(dz.cuda(), 1), wd, (3, 3), 1, 1, None, None, None, False, None, 1, None, 1)
+    out = ops.nhwc_to_nchw(dx, 1).cpu()
+    tag = "x".join(str(c) for c in cfg)
+    assert report("k8k_dgrad_max_rel_" + tag, (out - ref).abs().max() / ref.abs().max()) <= BF16_OUT_TOL
+    assert report("k8k_dgrad_rel_l2_" + tag, (out - ref).norm() / ref.norm()) <= BF16_OUT_TOL / 3

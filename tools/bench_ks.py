@@ -39,6 +39,9 @@ def stamps():
         print("%-22s %4d | %s  %s  %s  %s  %s  %s  %s | %s" % (
             name, len(t), f(t[:, 0] - t0), f(t[:, 1] - t[:, 0]), f(t[:, 2] - t[:, 1]), f(t[:, 3] - t[:, 2]),
             f(t[:, 4] - t[:, 3]), f(t[:, 5] - t[:, 4]), f(t[:, 6] - t[:, 5]), f(t[:, 6] - t[:, 0])))
+        clk = t[:, 7] * 100.0  # slot 7: s_memtime ticks over the main phase
+        print("%-22s        main phase: %.0f s_memtime ticks (median) = %.1f per MFMA of a wave; ticks per us of s_memrealtime %.0f"
+              % ("", np.median(clk), np.median(clk) / 180.0, np.median(clk / np.maximum(t[:, 3] - t[:, 2], 1e-3))))
 
 
 def main():
