@@ -480,12 +480,17 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
     want_graph = graph_env
     bucket = dp.make_bucket(m) if world > 1 else None
     params = bucket.params if bucket is not None else [p for p in m.parameters() if p.requires_grad]
-    try:  # the fused single-kernel Adam (same update rule as train.py:42's torch.optim.Adam) where the build has it
-        opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-8, capturable=want_graph, fused=True)
-        adam = "fused"
-    except Exception:
-        opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-8, capturable=want_graph)
-        adam = "foreach"
+    if os.environ.get("LSS_TRAIN_OPT", "clipadam") == "clipadam":
+        # clip_grad_norm_ + Adam (train.py:41, 62-63: same update rule) as three HIP launches (csrc/optim.hip)
+        opt = L.ClipAdam(params, lr=1e-4, weight_decay=1e-8)
+        adam = "ClipAdam (csrc/optim.hip: norm partials, finalize, clipped Adam update; LSS_TRAIN_OPT=torch = torch.optim.Adam)"
+    else:
+        try:  # torch's fused multi-tensor Adam where the build has it (A/B)
+            opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-8, capturable=want_graph, fused=True)
+            adam = "torch fused"
+        except Exception:
+            opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-8, capturable=want_graph)
+            adam = "torch foreach"
     tgt = torch.randint(0, 4, (B, 200, 200), device=dev)
     weight = torch.tensor([1.0, 10.0, 5.0, 10.0], device=dev)         # ref: src/tools.py:234
 
@@ -561,8 +566,8 @@ def train_leg(args, model, feats, calib, dev, dist, world, B):
                     "residual + ReLU unit of BevEncode (95 % of its FLOPs) is one HIP autograd node: conv fwd / dgrad / "
                     "wgrad, BN fwd / bwd, fused upsample+concat and its adjoint (LSS_TRAIN_NATIVE=0 = library path for "
                     "A/B); the 7x7/2 stem, the 3x3/2 convs and the 1x1/2 shortcuts run forward, dgrad and wgrad on the same HIP kernels "
-                    "over phase planes; 1x1 head + weighted cross-entropy = one HIP kernel per direction; library ops left: the two "
-                    "fp32 depthnet GEMMs of the lift-splat backward, Adam (fused), clip"}
+                    "over phase planes; 1x1 head + weighted cross-entropy = one HIP kernel per direction; clip + Adam = three HIP "
+                    "launches (optim.ClipAdam); library ops left: the two fp32 depthnet GEMMs of the lift-splat backward"}
 
 
 def host_cores():

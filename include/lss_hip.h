@@ -425,6 +425,19 @@ int lss_conv_bn_act_train_bwd(const void* dy, const void* y, const void* z, cons
                               void* stream);
 
 /* ---------------------------------------------------------------------------
+ * K10  gradient-norm clip + Adam over a list of fp32 tensors (training; replaces
+ *      torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm) + torch.optim.Adam.step(), train.py:41, 62-63)
+ *      in three launches: chunk sums of squares, one-workgroup finalize (norm, clip coefficient, step counter, bias
+ *      corrections), clipped Adam update.  `tensors`: HOST array of `count` records
+ *          { float* p; float* g; float* m; float* v; long long n; }      (device pointers, contiguous fp32)
+ *      passed on by value in the kernel arguments.  state: 8 device floats, zero before the first step: [0] step
+ *      count, [1] total gradient norm before the clip, [2] clip coefficient.  partials: lss_clip_adam_partials()
+ *      device floats.  max_norm <= 0: no clip.  g is overwritten with the clipped gradient. */
+long long lss_clip_adam_partials(const long long* numel, int count);
+int lss_clip_adam_step(const void* tensors, int count, float* state, float* partials, long long n_partials, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, float max_norm, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Weighted cross-entropy over NCHW logits.
  * replaces: nn.CrossEntropyLoss(weight)(ypred, ytgt) of SimpleLoss / MultiLoss, src/tools.py:221-238
  *           (log_softmax + nll_loss2d, forward and backward).

@@ -10,8 +10,9 @@ from .model_vovnet_transformer import (BEVEncoderTransformer, CamEncodeV2, Multi
                                        StandardDepthNet, VoVNetBEVTransformer,
                                        compile_model_vovnet_transformer)
 from .transformer_modules import LightweightBEVTransformer  # noqa: F401
+from .optim import ClipAdam  # noqa: F401
 
-__all__ = ["gen_dx_bx", "cumsum_trick", "QuickCumsum", "SimpleLoss", "MultiLoss", "CalibrationPack",
+__all__ = ["ClipAdam", "gen_dx_bx", "cumsum_trick", "QuickCumsum", "SimpleLoss", "MultiLoss", "CalibrationPack",
            "prepare_calibration", "enable_sync_bn", "Up", "Encoder", "CamEncode", "BevEncode", "LSS", "BEV_TXT",
            "compile_model_lss", "compile_model_bevtxt", "compile_model_onlybev", "StandardDepthNet", "MultiScaleDepthNet", "CamEncodeV2",
            "BEVEncoderTransformer", "LightweightBEVTransformer", "VoVNetBEVTransformer",

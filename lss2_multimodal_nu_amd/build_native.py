@@ -33,6 +33,7 @@ SOURCES = {
     "conv_wgrad.hip": [],
     "bn_train.hip": [],
     "loss.hip": [],
+    "optim.hip": [],
     "rccl_bucket.hip": [],  # host code only: RCCL resolved with dlsym at run time (no -lrccl)
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-variable",

@@ -262,12 +262,27 @@ def train_step(model, bucket, opt, loss_fn, inputs, clip=5.0):
     loss = loss_fn(model(*inputs))
     loss.backward()
     bucket.all_reduce_mean()
-    _last_norm[0] = bucket.clip_grad_norm_(clip)
-    unused = bucket.hide_unused()
-    opt.step()
+    _clip_and_step(opt, bucket, None, clip)
+    return loss.detach()
+
+
+def _clip_and_step(opt, bucket, params, clip):
+    """clip_grad_norm_(clip) + opt.step() (train.py:62-63).  optim.ClipAdam does both in three launches; any other
+    optimizer gets the clip on the flat buffer (bucket) or torch's foreach form (no host sync), then its own step.
+    Leaves the total norm before the clip in `_last_norm[0]` (a device tensor)."""
+    from .optim import ClipAdam
+    unused = bucket.hide_unused() if bucket is not None else None
+    if isinstance(opt, ClipAdam):
+        opt.step(max_grad_norm=clip)
+        _last_norm[0] = opt.grad_norm
+    else:
+        if bucket is not None:
+            _last_norm[0] = bucket.clip_grad_norm_(clip)
+        else:
+            _last_norm[0] = torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], clip, foreach=True)
+        opt.step()
     if unused:
         bucket.attach()
-    return loss.detach()
 
 
 _last_norm = [None]  # total gradient 2-norm BEFORE the clip of the latest step (a device tensor: no host sync)
@@ -284,8 +299,7 @@ def train_step_local(model, opt, loss_fn, inputs, clip=5.0):
         p.grad = None
     loss = loss_fn(model(*inputs))
     loss.backward()
-    _last_norm[0] = torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], clip, foreach=True)
-    opt.step()
+    _clip_and_step(opt, None, params, clip)
     return loss.detach()
 
 
@@ -299,7 +313,8 @@ class GraphedTrainStep:
     replay: the feature tensor, the targets the loss function closes over (pass them as `(static_device_tensor,
     new_value)` pairs through `__call__(..., refresh=...)`), and the calibration as a device-resident
     `CalibrationPack` (host inverses as always, data.prepare_calibration; one H2D copy per step).  The optimizer
-    must be built with `capturable=True`.
+    must be optim.ClipAdam (clip + Adam in three launches, device-resident step counter) or a torch optimizer built
+    with `capturable=True`.
 
     One process: ONE graph [zero / drop grads, forward, loss, backward, clip, Adam].
     Data parallel (`bucket` over a group of more than one rank): graph A = [zero the flat buffer, forward, loss,
@@ -364,11 +379,8 @@ class GraphedTrainStep:
                 bucket.capturing = False
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, pool=self.graph.pool(), capture_error_mode="thread_local"):
-                self.grad_norm = bucket.clip_grad_norm_(clip)
-                unused = bucket.hide_unused()
-                opt.step()
-                if unused:
-                    bucket.attach()
+                _clip_and_step(opt, bucket, None, clip)
+                self.grad_norm = _last_norm[0]
         self._self_check()
 
     def _replay(self):

@@ -1,0 +1,89 @@
+"""K10, optim.ClipAdam (csrc/optim.hip): clip_grad_norm_ + Adam of the reference's loop (train.py:41, 62-63) in three
+launches, against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam on the same tensors and gradients, step by step."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(64, 64, 3, 3), (128,), (1,), (3,), (4099,), (256, 320, 3, 3), (4, 128, 1, 1), (7, 5), (4096,), (8193,)]
+
+
+def _problem(seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    params = [torch.randn(*s, generator=g).cuda() for s in SHAPES]
+    grads = [[(torch.randn(*s, generator=g) * scale).cuda() for s in SHAPES] for _ in range(6)]
+    return params, grads
+
+
+@pytest.mark.parametrize("cfg", [(5.0, 1e-2, 1.0), (5.0, 0.0, 1e-3), (None, 1e-7, 1.0), (0.05, 1e-7, 10.0)])
+def test_clip_adam_equals_torch_clip_plus_adam(cfg, report):
+    """cfg = (max_grad_norm, weight_decay, gradient scale): clip active (norm >> 5), inactive (norm << 5), off."""
+    from lss2_multimodal_nu_amd import ClipAdam
+    clip, wd, scale = cfg
+    p0, grads = _problem(3, scale)
+    pa = [torch.nn.Parameter(p.clone()) for p in p0]
+    pb = [torch.nn.Parameter(p.clone()) for p in p0]
+    ours = ClipAdam(pa, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd, max_grad_norm=clip)
+    ref = torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd)
+    worst = 0.0
+    for step, gs in enumerate(grads):
+        for p, q, g in zip(pa, pb, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        ours.step()
+        norm_ref = torch.nn.utils.clip_grad_norm_(pb, clip) if clip else torch.linalg.vector_norm(torch.cat([g.reshape(-1) for g in gs]))
+        ref.step()
+        assert abs(float(ours.grad_norm) - float(norm_ref)) <= 2e-6 * float(norm_ref)
+        for p, q in zip(pa, pb):
+            worst = max(worst, float((p - q).abs().max() / (q.abs().max() + 1e-12)))
+            if clip:   # `.grad` holds the clipped gradient afterwards, as after clip_grad_norm_
+                assert torch.allclose(p.grad, q.grad, rtol=2e-6, atol=1e-12)
+    assert report("k10_clip_adam_max_rel_%s" % "_".join(str(c) for c in cfg), worst) <= 5e-6
+    sd = ours.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == len(grads)
+
+
+def test_clip_adam_skips_parameters_without_gradient_and_refuses_bad_tensors():
+    from lss2_multimodal_nu_amd import ClipAdam
+    a, b = torch.nn.Parameter(torch.ones(10).cuda()), torch.nn.Parameter(torch.ones(10).cuda())
+    opt = ClipAdam([a, b], lr=0.1)
+    a.grad = torch.ones(10).cuda()
+    opt.step()
+    assert torch.equal(b.detach(), torch.ones(10).cuda()) and float(a.detach()[0]) < 1.0
+    c = torch.nn.Parameter(torch.ones(10).cuda().half())
+    c.grad = torch.ones(10).cuda().half()
+    with pytest.raises(ValueError):
+        ClipAdam([c]).step()
+    with pytest.raises(ValueError):
+        ClipAdam([a], lr=-1.0)
+
+
+def test_clip_adam_replays_in_a_graph_like_eager():
+    """The whole step in a HIP graph (device-resident step counter): five replays == five eager steps, bit for bit."""
+    from lss2_multimodal_nu_amd import ClipAdam
+    p0, grads = _problem(5, 1.0)
+
+    def run(graphed):
+        ps = [torch.nn.Parameter(p.clone()) for p in p0]
+        static_g = [torch.zeros_like(p) for p in ps]
+        for p, g in zip(ps, static_g):
+            p.grad = g
+        opt = ClipAdam(ps, lr=1e-2, weight_decay=1e-3, max_grad_norm=5.0)
+        for g, src in zip(static_g, grads[0]):
+            g.copy_(src)
+        opt.step()   # warm-up step (state allocation) outside the capture
+        graph = None
+        if graphed:
+            for g, src in zip(static_g, grads[1]):
+                g.copy_(src)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):   # (recorded, not run: the replays below do every step from grads[1] on)
+                opt.step()
+        for gs in grads[1:]:
+            for g, src in zip(static_g, gs):
+                g.copy_(src)
+            graph.replay() if graphed else opt.step()
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in ps]
+
+    a, b = run(False), run(True)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
