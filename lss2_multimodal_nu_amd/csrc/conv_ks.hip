@@ -134,14 +134,24 @@ __global__ __launch_bounds__(256, 1) void conv_ks_kernel(const KsArgs a) {
   }
 
   // ---- weights: this wave's KSW x 2 A fragments, straight into registers (coalesced 1-KiB loads) ----
+  // Only the first WPRE k-steps are requested here; the main phase requests k-step s + WPRE while it computes k-step s
+  // (two 1-KiB loads per 10-20 MFMAs: nothing next to the LDS-DMA burst of the prologue).  The prologue is a fill-rate
+  // problem - every CU pulls its patch AND its 72-144 KiB of weights at once, ~70 GB/s per CU - so bytes that can
+  // arrive during the MFMAs should: with everything requested up front (-DKS_WPRE_ALL, the first form of this kernel)
+  // kernel entry -> operands landed took 3.0-3.6 us of the 7-9.
+#ifdef KS_WPRE_ALL
+  constexpr int WPRE = KSW;
+#else
+  constexpr int WPRE = KSW >= 18 ? 8 : 5;
+#endif
   bf16x8 wf[KSW][2];
-  {
-    const unsigned char* wp = a.w + ((size_t)(cb * NKW + kp) * KSW * 2) * 1024 + lane * 16;
+  const unsigned char* wp = a.w + ((size_t)(cb * NKW + kp) * KSW * 2) * 1024 + lane * 16;
+  auto load_w = [&](int s) {
 #pragma unroll
-    for (int s = 0; s < KSW; ++s)
+    for (int ct = 0; ct < 2; ++ct) wf[s][ct] = *reinterpret_cast<const bf16x8*>(wp + (s * 2 + ct) * 1024);
+  };
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) wf[s][ct] = *reinterpret_cast<const bf16x8*>(wp + (s * 2 + ct) * 1024);
-  }
+  for (int s = 0; s < WPRE; ++s) load_w(s);
 
   // ---- per-lane patch offsets of the wave's pixel tiles (pixel n of tile j; tap (ky, kx) adds (ky WP + kx) 64) ----
   // and the residual pieces of the tiles this wave will finish (requested now: long landed when the epilogue wants them)
@@ -200,6 +210,7 @@ __global__ __launch_bounds__(256, 1) void conv_ks_kernel(const KsArgs a) {
   load_frags(0, 0);
 #pragma unroll
   for (int s = 0; s < KSW; ++s) {
+    if (s + WPRE < KSW) load_w(s + WPRE);
 #ifndef KS_DIAG_NOREAD                                // timing-only diagnostic builds (tools/build_diag_libs.sh KS_NOREAD ..)
     if (s + 1 < KSW) load_frags((s + 1) & 1, s + 1);
 #endif

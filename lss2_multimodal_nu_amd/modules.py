@@ -138,6 +138,32 @@ def _s2_tables(device, K):
     return idx
 
 
+_s2_gather_index = {}
+
+
+def _s2_wgrad_gather(g6, K):
+    """(Co, C, K, K) weight gradient out of K9w's phase-plane result g6 = [co][py][px][ci][ty][tx] (T x T taps): kernel
+    row ky lives at phase ph[ky], tap tp[ky].  One `index_select` over a cached flat index (the advanced-indexing
+    form g6[:, ph[:, None], ph[None, :], :, tp[:, None], tp[None, :]] costs six launches per call: four index
+    preparations, the gather, the permute copy - 15 of a training step's launches over its three K > 1 stride-2 convs)."""
+    Co, _, _, C, T, _ = g6.shape
+    key = (str(g6.device), Co, C, K, T)
+    idx = _s2_gather_index.get(key)
+    if idx is None:
+        if g6.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("stride-2 gather index %s is not built yet and a stream capture is active: run one eager "
+                               "training step (or modules.warm_s2_tables) before capturing" % (key,))
+        ph = torch.tensor([(k - K // 2) % 2 for k in range(K)])
+        ds = [(k - K // 2) // 2 for k in range(K)]
+        tp = torch.tensor([d - min(ds) for d in ds])
+        co = torch.arange(Co).view(Co, 1, 1, 1)
+        ci = torch.arange(C).view(1, C, 1, 1)
+        ky, kx = torch.arange(K).view(1, 1, K, 1), torch.arange(K).view(1, 1, 1, K)
+        flat = ((((co * 2 + ph[ky]) * 2 + ph[kx]) * C + ci) * T + tp[ky]) * T + tp[kx]
+        idx = _s2_gather_index[key] = flat.reshape(-1).to(g6.device)
+    return g6.reshape(-1).index_select(0, idx).view(Co, C, K, K)
+
+
 def warm_s2_tables(device):
     for K in (1, 3, 7):
         _s2_tables(device, K)
@@ -155,13 +181,11 @@ def conv_s2_wgrad_phase_planes(xn, gyn, K):
     xs = xn.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // 2, W // 2, 4 * C)
     ph, tp = _s2_tables(xn.device, K)
     if K == 7:  # the stem: taps d in {-2 .. 1} -> the 4x4-tap form of K9w (two launches of eight consumer waves)
-        g6 = ops.conv4x4_wgrad(xs, gyn).view(Co, 2, 2, C, 4, 4)
-        return g6[:, ph[:, None], ph[None, :], :, tp[:, None], tp[None, :]].permute(2, 3, 0, 1).contiguous()
+        return _s2_wgrad_gather(ops.conv4x4_wgrad(xs, gyn).view(Co, 2, 2, C, 4, 4), K)
     g6 = ops.conv3x3_wgrad(xs, gyn).view(Co, 2, 2, C, 3, 3)   # [co][py][px][ci][ty][tx], tap t = d + 1
     if K == 1:
         return g6[:, 0, 0, :, 1, 1].reshape(Co, C, 1, 1).contiguous()
-    # advanced indices separated by a slice: the broadcast (ky, kx) dimensions come first
-    return g6[:, ph[:, None], ph[None, :], :, tp[:, None], tp[None, :]].permute(2, 3, 0, 1).contiguous()
+    return _s2_wgrad_gather(g6, K)
 
 
 def conv_s2_dgrad_phase_planes(gyn, weight, pad, H, W):

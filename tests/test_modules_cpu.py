@@ -287,3 +287,18 @@ def test_conv_s2_backward_gemm_equals_autograd():
         gx, gw = conv_s2_backward_gemm(gy, x.detach(), w.detach(), pad)
         assert torch.allclose(gx, x.grad, rtol=1e-4, atol=1e-4), K
         assert torch.allclose(gw, w.grad, rtol=1e-4, atol=1e-4), K
+
+
+def test_s2_wgrad_gather_equals_advanced_indexing():
+    """modules._s2_wgrad_gather (one index_select over a cached flat index) against the advanced-indexing form it
+    replaced, for the 3x3 / 2 convs (3 taps per axis) and the 7x7 / 2 stem (4 taps)."""
+    import torch
+    from lss2_multimodal_nu_amd import modules as M
+    for K, T in ((3, 3), (7, 4)):
+        Co, C = 8, 6
+        g6 = torch.randn(Co, 2, 2, C, T, T)
+        ph = torch.tensor([(k - K // 2) % 2 for k in range(K)])
+        ds = [(k - K // 2) // 2 for k in range(K)]
+        tp = torch.tensor([d - min(ds) for d in ds])
+        ref = g6[:, ph[:, None], ph[None, :], :, tp[:, None], tp[None, :]].permute(2, 3, 0, 1).contiguous()
+        assert torch.equal(M._s2_wgrad_gather(g6, K), ref)

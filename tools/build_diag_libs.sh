@@ -10,7 +10,7 @@ cd "$(dirname "$0")/../lss2_multimodal_nu_amd/csrc"
 mkdir -p ../../diag_libs /tmp/lss_diag
 for v in STATS NOBLEND NOWDMA "$@"; do
   case "$v" in KS_*)   # timing-only builds of the K-split kernel: KS_NOREAD (fragments read once), KS_NOMFMA (reads only)
-    /opt/rocm/bin/hipcc -c conv_ks.hip -o /tmp/lss_diag/conv_ks_$v.o -O3 -fPIC -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -I../../include -DKS_DIAG_${v:3}
+    /opt/rocm/bin/hipcc -c conv_ks.hip -o /tmp/lss_diag/conv_ks_$v.o -O3 -fPIC -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -I../../include $([ "$v" = KS_WPRE_ALL ] && echo -DKS_WPRE_ALL || echo -DKS_DIAG_${v:3})
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../diag_libs/liblss_$v.so $(ls build/*.o | grep -v conv_ks.o) /tmp/lss_diag/conv_ks_$v.o -ldl
     continue;;
   esac
