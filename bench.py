@@ -302,6 +302,7 @@ def main():
     spl_gbs = splat_bytes_step * args.steps / (ms_spl * 1e-3) / 1e9 if ms_spl else 0.0
 
     conv_traffic, splat_traffic = pmc_traffic("conv_"), pmc_traffic("region_splat_kernel")
+    l1_launches = 3 if os.environ.get("LSS_SPLAT_DIRECT") == "0" else 2   # (splat.hip: the direct form is the default)
     # the dominant kernel by itself: algorithmic FLOPs of ONE launch / its own average duration
     dom_flops = 2.0 * B * X * Y * 128 * (256 * 9 + 4)   # 3x3 256 -> 128 on the upsampled grid + the 1x1 head (4 classes)
     dom_us = ms_dom * 1e3 / n_dom if n_dom else 0.0
@@ -333,21 +334,24 @@ def main():
                                          "-> BevEncode -> 400x400x4" % B}[args.workload],
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d (sample-sharded, no collective)" % world,
                    "precision": args.precision, "spinup_ms": args.spinup_ms, "calibration": "CPU tensors per step; 3x3 inverses on host (exact-index contract), 576 floats passed in the kernel arguments (no H2D copy)"},
-        "roofline": {"kernel": "conv_lds_kernel / conv_ring_kernel: the 16 BevEncode launches of a step (stride-2 convs carry their 1x1 downsample, up2 its head; "
-                               "the three big 3x3 layers run on the ring kernel), one HIP-event "
+        "roofline": {"kernel": "conv_lds_kernel / conv_ks_kernel / conv_ring_kernel: the 16 BevEncode launches of a step (stride-2 convs carry their 1x1 downsample, "
+                               "up2 its head; the ten 3x3 / stride-1 convs of layer1-3 run on the K-split one-pass kernel, the three big 3x3 layers on the ring kernel), one HIP-event "
                                "bracket around the group (per-launch brackets cost ~10 us of idle each)",
                      "bound": "mfma", "achieved": conv_tf, "peak": peak_tf, "unit": "TFLOP/s",
                      "frac": conv_tf / peak_tf, "traffic": conv_traffic[0], "traffic_unit": "HBM bytes per launch (PMC)",
                      "traffic_source": conv_traffic[1], "launches": n_conv * 16,
                      "avg_us": ms_conv * 1e3 / max(n_conv * 16, 1), "flops_per_step": conv_flops_step,
                      "dominant_kernel": dominant},
-        "roofline_l1": {"kernel": "lift-splat level = depthnet_rows_and_voxels (K2 || K3) + region_fill + region_splat "
-                                  "(3 launches, one HIP-event bracket); `traffic` is region_splat_kernel's own",
+        "roofline_l1": {"kernel": ("lift-splat level = depthnet_rows_and_voxels (K2 || K3, writes the region entries itself) + "
+                                   "region_splat (direct form: 2 launches, one HIP-event bracket); `traffic` is region_splat_kernel's own"
+                                   if l1_launches == 2 else
+                                   "lift-splat level = depthnet_rows_and_voxels (K2 || K3) + region_fill + region_splat "
+                                   "(3 launches, one HIP-event bracket); `traffic` is region_splat_kernel's own"),
                         "bound": "hbm", "achieved": spl_gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": spl_gbs / HBM_PEAK_GBS, "traffic": splat_traffic[0],
                         "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": splat_traffic[1],
-                        "launches": n_spl * 3,
-                        "avg_us": ms_spl * 1e3 / max(n_spl * 3, 1), "level_us": ms_spl * 1e3 / max(n_spl, 1),
+                        "launches": n_spl * l1_launches,
+                        "avg_us": ms_spl * 1e3 / max(n_spl * l1_launches, 1), "level_us": ms_spl * 1e3 / max(n_spl, 1),
                         "bytes_per_step": splat_bytes_step},
         "per_rank_fps": per_rank, "comm": comm,
         "levels": {"L2_hot_path_fps": fps,

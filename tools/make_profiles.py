@@ -95,7 +95,9 @@ def main():
                      ("ring_microbench_nowdma.txt", "ring_microbench_nowdma.txt"),
                      ("ring_microbench_readsonly.txt", "ring_microbench_readsonly.txt"),
                      ("ring_microbench_oneread.txt", "ring_microbench_oneread.txt"),
-                     ("wgrad_microbench.txt", "wgrad_microbench.txt")):
+                     ("wgrad_microbench.txt", "wgrad_microbench.txt"), ("ks_microbench.txt", "ks_microbench.txt"),
+                     ("ks_stamps.txt", "ks_stamps.txt"), ("ks_stamps_diag.txt", "ks_stamps_diag.txt"),
+                     ("graph_node_cost.txt", "graph_node_cost.txt"), ("train_step_trace.txt", "train_step_trace.txt")):
         p = os.path.join(src, tag)
         if os.path.exists(p):
             try:

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 ROUND=${ROUND:-r04}
 # the diagnostic builds must carry the ABI of the shipped library (built together by tools/build_diag_libs.sh in the
 # build container, BEFORE the gpurun call): a stale one would leave tracebacks where measurements belong
-python $R/tools/check_diag_abi.py || { echo "diag_libs/ do not match liblss_hip.so: run tools/build_diag_libs.sh STATS NOBLEND NOWDMA READSONLY ONEREAD first"; exit 1; }
+python $R/tools/check_diag_abi.py || { echo "diag_libs/ do not match liblss_hip.so: run tools/build_diag_libs.sh READSONLY ONEREAD KS_NOREAD KS_NOMFMA KS_WPRE_ALL first"; exit 1; }
 OUT=$R/gpurun_out/prof_$ROUND
 rm -rf "$OUT" && mkdir -p "$OUT"
 ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-train --no-two-streams"  # profiled runs: the single-stream loop only
@@ -30,6 +30,12 @@ python tools/bench_ring.py > $OUT/ring_microbench.txt 2>&1
 [ -f diag_libs/liblss_READSONLY.so ] && LSS_HIP_LIB=$R/diag_libs/liblss_READSONLY.so python tools/bench_ring.py > $OUT/ring_microbench_readsonly.txt 2>&1
 [ -f diag_libs/liblss_ONEREAD.so ] && LSS_HIP_LIB=$R/diag_libs/liblss_ONEREAD.so python tools/bench_ring.py > $OUT/ring_microbench_oneread.txt 2>&1
 python tools/bench_wgrad.py > $OUT/wgrad_microbench.txt 2>&1
+python tools/bench_ks.py > $OUT/ks_microbench.txt 2>&1
+python tools/bench_ks.py --stamps > $OUT/ks_stamps.txt 2>&1
+for v in KS_NOREAD KS_NOMFMA KS_WPRE_ALL; do
+  [ -f diag_libs/liblss_$v.so ] && { echo "--- $v"; LSS_HIP_LIB=$R/diag_libs/liblss_$v.so python tools/bench_ks.py --stamps; LSS_HIP_LIB=$R/diag_libs/liblss_$v.so python tools/bench_ks.py; } >> $OUT/ks_stamps_diag.txt 2>&1
+done
+python tools/graph_node_cost.py > $OUT/graph_node_cost.txt 2>&1
 echo "microbenches done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $R/bench.py $ARGS > $OUT/kt.log 2>&1
@@ -42,5 +48,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_hires -- python 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_fp32 -- python $R/bench.py --precision fp32 --steps 10 --warmup 3 --no-cpu-baseline --no-train --no-two-streams > $OUT/kt_fp32.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_train -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-two-streams --train-steps 10 > $OUT/kt_train.log 2>&1
 cd $R
+python tools/train_step_trace.py $(find $OUT/kt_train -name "*kernel_trace.csv" | head -1) 70 > $OUT/train_step_trace.txt 2>&1
 find $OUT -name "*.csv" | wc -l
 tail -c 600 $OUT/bench_line.json
