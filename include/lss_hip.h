@@ -502,8 +502,10 @@ int lss_lift_splat_from_heads(const float* frustum, const float* inv_post_rots, 
  * with one more workspace: `direct_entries` (lss_lift_splat_direct_bytes(...) bytes, 8-byte aligned, contents
  * irrelevant).  With it the region pipeline runs as TWO launches - the geometry workgroups write their points straight
  * into fixed-capacity per-region buckets, the splat gathers the depth weights itself - instead of three (no fill
- * launch).  A region that overflows its bucket (degenerate calibrations only) is rebuilt from the voxel ids: results
- * are the exact, order-independent fixed-point sums either way.  NULL / too small: the three-launch form.
+ * launch).  A region that overflows its bucket (1024 points; hi-res rigs do, next to the ego vehicle) sends the rest
+ * to one overflow list in the same workspace (65 536 records); if that overflows too (degenerate calibrations only) the
+ * region is rebuilt from the voxel ids: results are the exact, order-independent fixed-point sums every way.  NULL / too
+ * small: the three-launch form.
  *   calib_host != NULL : host calibration, B*N <= 36 (inv_post_rots .. trans ignored), f32 depthnet math only
  *   x == NULL          : depth (B*N, D, fH, fW) and feat (B*N*fH*fW, C) are INPUTS (the vovnet heads' form) */
 typedef struct lss_lift_splat_desc {

@@ -85,6 +85,9 @@ struct RegionArgs {
   int nRy, rps;
   int2* dentries;         // DIRECT form (region_plan.h): the geometry workgroups write the entries; else nullptr
   int cap, HW;            // slots per region; pixels per camera image
+  int4* ovf;              // DIRECT form: the overflow list (points beyond their region's bucket), or nullptr
+  int32_t* ovf_ctl;       // {records appended, regions over capacity, -}
+  int ovf_cap;
 };
 
 // one thread per frustum point of camera image bn; tile_x = 256-point block within the image.
@@ -148,17 +151,36 @@ __device__ __forceinline__ void points_to_voxels_body(
       const int c = hist[i];
       if (c > 0) {
         const int base = atomicAdd(rg->region_count + b * rg->rps + i, c);
-        if (direct) hist[i] = base;
+        if (direct) {
+          hist[i] = base;
+          // exactly one group of an over-capacity region holds slot number `cap`: it counts the region in
+          if (base <= rg->cap && rg->cap < base + c) atomicAdd(rg->ovf_ctl + 1, 1);
+        }
       }
     }
     if (direct) {
       __syncthreads();
+      bool spill = false;
+      int key = 0;
       if (v >= 0) {
         const int slot = hist[region] + rank;
-        if (slot < rg->cap) {  // (a fuller region keeps only its count: the splat takes it from the voxel ids)
-          const int d = f / rg->HW, pix = f - d * rg->HW;
-          rg->dentries[(size_t)(b * rg->rps + region) * rg->cap + slot] =
-              make_int2(((bn * rg->HW + pix) << 8) | cell, bn * DHW + f);
+        const int d = f / rg->HW, pix = f - d * rg->HW;
+        key = ((bn * rg->HW + pix) << 8) | cell;
+        if (slot < rg->cap)
+          rg->dentries[(size_t)(b * rg->rps + region) * rg->cap + slot] = make_int2(key, bn * DHW + f);
+        else
+          spill = true;  // the bucket is full: this point goes to the overflow list
+      }
+      // one global atomic per wave that has spilling points (a wave-wide ballot: every lane is here)
+      const unsigned long long mask = __ballot(spill);
+      if (mask != 0 && rg->ovf != nullptr) {
+        const int lane = threadIdx.x & 63, leader = __builtin_ctzll(mask);
+        int ob = 0;
+        if (lane == leader) ob = atomicAdd(rg->ovf_ctl, (int)__builtin_popcountll(mask));
+        ob = __builtin_amdgcn_readlane(ob, leader);
+        if (spill) {
+          const int o = ob + (int)__builtin_popcountll(mask & ((1ULL << lane) - 1ULL));
+          if (o < rg->ovf_cap) rg->ovf[o] = make_int4(b * rg->rps + region, key, bn * DHW + f, 0);
         }
       }
     }
@@ -577,8 +599,9 @@ static int depthnet_voxels_impl(const float* frustum, const float* inv_post_rots
     a.rg.region_start = plan->region_start;
     a.rg.wg_absmax = plan->wg_absmax; a.rg.nRy = plan->nRy; a.rg.rps = plan->rps;
     a.rg.dentries = reinterpret_cast<int2*>(plan->dentries); a.rg.cap = plan->cap; a.rg.HW = fH * fW;
+    a.rg.ovf = reinterpret_cast<int4*>(plan->ovf); a.rg.ovf_ctl = plan->ovf_ctl; a.rg.ovf_cap = plan->ovf_cap;
   } else {
-    a.rg = RegionArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0};
+    a.rg = RegionArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0};
   }
   a.gx3 = lss_cdiv(DHW, 256);
   const long long nblk = (long long)a.n2 + (long long)a.gx3 * B * N;
@@ -710,6 +733,7 @@ int lss_region_voxels_absmax(const float* frustum, const float* inv_post_rots, c
   a.rg.region_count = plan.region_count; a.rg.region_cursor = plan.region_cursor; a.rg.region_start = plan.region_start;
   a.rg.wg_absmax = plan.wg_absmax; a.rg.nRy = plan.nRy; a.rg.rps = plan.rps;
   a.rg.dentries = reinterpret_cast<int2*>(plan.dentries); a.rg.cap = plan.cap; a.rg.HW = fH * fW;
+  a.rg.ovf = reinterpret_cast<int4*>(plan.ovf); a.rg.ovf_ctl = plan.ovf_ctl; a.rg.ovf_cap = plan.ovf_cap;
   a.gx3 = lss_cdiv(DHW, 256);
   const long long nblk = (long long)a.n2 + (long long)a.gx3 * B * N;
   if (nblk >= (1LL << 31)) return LSS_E_SHAPE;

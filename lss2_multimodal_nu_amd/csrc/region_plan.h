@@ -18,9 +18,19 @@ struct LssRegionPlan {
   // DIRECT form (round 4; dentries != nullptr): launch 1 writes the entries itself, at FIXED per-region offsets -
   // region r owns dentries[r * cap .. (r + 1) * cap) as {(feature row << 8) | cell in region, point id} - and launch 2
   // (the fill) does not exist: the splat reads region_count[r], its slots, and depth[point id].  A region with more
-  // than `cap` points keeps only its count; the splat then takes that region from the voxel ids of its sample.
+  // than `cap` points keeps its first `cap` there; the rest goes to the overflow list below.
   int32_t* dentries;
   int cap;
+  // ... and the points that did not fit go to ONE overflow list behind the buckets: {region, key, point id, -} records
+  // appended with one global atomic per WAVE that has any.  ovf_ctl (three of the zero-between-calls words: the
+  // region_cursor words, which the direct form does not use) = {records appended, regions over capacity, such regions
+  // the splat has finished}; the last of those splat workgroups clears all three.  An over-capacity region = its full
+  // bucket + its records of the list (hi-res rigs put 1 000-2 000 points into the regions next to the ego vehicle: the
+  // list holds a few thousand records); only when the LIST overflows (ovf_cap records) is such a region rebuilt from
+  // the voxel ids of its sample.
+  int32_t* ovf;
+  int32_t* ovf_ctl;
+  int ovf_cap;
 };
 
 constexpr int LSS_REGION_SIDE = 8;  // cells per region side

@@ -310,8 +310,9 @@ __device__ __forceinline__ void region_accumulate_careful(const float* __restric
 // fill launch, no region_start - and the depth weight is gathered from depth[point id] beside the entry load; the
 // maximum over K2's per-workgroup |feature| maxima (what the fill kernel's first workgroup used to reduce) is taken
 // by every workgroup from the n2 slots (1 KB, L2-resident) while its other loads fly.  A region whose count exceeds
-// `cap` is rebuilt from the voxel ids of its sample (region_accumulate_scan): exact, slow, and only reachable with
-// degenerate calibrations.
+// `cap` takes its full bucket plus its records of the overflow list (region_plan.h; hi-res rigs do this every frame);
+// only if the list itself overflowed is it rebuilt from the voxel ids of its sample (region_accumulate_scan): exact,
+// slow, and only reachable with degenerate calibrations.
 struct DirectArgs {
   const float* depth;      // (B*N, D, HW): flat index = point id
   const int32_t* voxel;    // point id -> voxel id or -1
@@ -341,6 +342,45 @@ __device__ __forceinline__ void region_accumulate_scan(const float* __restrict__
           key = ((bn * da.HW + pix) << 8) | ((((ix & 7) << 3) | (iy & 7)) * Z + iz);
           w = da.depth[p];
         }
+      }
+    }
+    unsigned long long todo = __ballot(key >= 0);
+    while (todo) {
+      const int i = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const int k = __builtin_amdgcn_readlane(key, i);
+      const float ww = rl_f(w, i);
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        const float x = ww * feat[(size_t)(k >> 8) * C + q * 64 + lane];
+        const int o = (k & 255) * C + q * 64 + lane;
+        if (!(fabsf(x) < limit)) {
+          atomicOr(&flags[o >> 5], 1u << (o & 31));
+        } else {
+          const double t = __builtin_fma((double)x, scale, FX_MAGIC);
+          atomicAdd(&tile[o], (unsigned long long)(__builtin_bit_cast(long long, t) - ((long long)FX_MAGIC_HI << 32)));
+        }
+      }
+    }
+  }
+}
+
+// the records of the overflow list that belong to region r (region_plan.h), element by element like the scan above:
+// finite products in fixed point, anything else flagged
+template <int CPL>
+__device__ __forceinline__ void region_accumulate_overflow(const float* __restrict__ feat, const DirectArgs& da,
+                                                           const int4* __restrict__ ovf, int novf, int r, double scale,
+                                                           float limit, unsigned long long* tile, unsigned int* flags,
+                                                           int wave, int lane) {
+  constexpr int C = 64 * CPL;
+  for (int i0 = wave * 64; i0 < novf; i0 += 256) {
+    int key = -1;
+    float w = 0.f;
+    if (i0 + lane < novf) {
+      const int4 rec = ovf[i0 + lane];
+      if (rec.x == r) {
+        key = rec.y;
+        w = da.depth[rec.z];
       }
     }
     unsigned long long todo = __ballot(key >= 0);
@@ -406,8 +446,12 @@ __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restri
     sw = da.depth[min((unsigned int)en.y, (unsigned int)(gridDim.x / rp.rps) * (unsigned int)(da.Ncam * da.DHW) - 1u)];
   }
   const int ntot = rp.region_count[r];                       // points of the region
-  const bool over = DIRECT && ntot > rp.cap;                 // more than its bucket holds: taken from the voxel ids
-  const int n = DIRECT ? (over ? 0 : ntot) : ntot;           // entries to stream
+  const bool over = DIRECT && ntot > rp.cap;                 // more than its bucket holds
+  // ... then: the full bucket + this region's records of the overflow list, unless the LIST overflowed (or there is
+  // none): only then is the region rebuilt from the voxel ids of its sample
+  const int novf = over ? rp.ovf_ctl[0] : 0;
+  const bool list_ok = over && rp.ovf != nullptr && novf <= rp.ovf_cap;
+  const int n = DIRECT ? (over ? (list_ok ? rp.cap : 0) : ntot) : ntot;   // entries to stream
   const int start = DIRECT ? r * rp.cap : rp.region_start[r];
   float m;  // max FINITE |feature| over K2's workgroups
   if (DIRECT) {
@@ -515,11 +559,27 @@ __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restri
         region_accumulate_careful<CPL>(feat, entries, start, n, scale, ldexpf(1.0f, min(e + 10, 127)), tile, flags, wave, lane);
       __syncthreads();
     }
-  } else if (over) {  // DIRECT, bucket overflow: the whole region from the voxel ids of its sample
+  } else if (over) {  // DIRECT, bucket AND list overflow: the whole region from the voxel ids of its sample
     for (int i = tid; i < zero_n; i += 256) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     region_accumulate_scan<CPL>(feat, da, b, rx, ry, X, Y, Z, scale, ldexpf(1.0f, min(e + 10, 127)), tile, flags, wave, lane);
     __syncthreads();
+  }
+  if (DIRECT && over) {
+    if (list_ok && wg_watch == 0) {  // (a careful re-run above has already taken every point of the region)
+      region_accumulate_overflow<CPL>(feat, da, reinterpret_cast<const int4*>(rp.ovf), novf, r, scale,
+                                      ldexpf(1.0f, min(e + 10, 127)), tile, flags, wave, lane);
+      __syncthreads();
+    }
+    // the last over-capacity region to get here puts the three control words back to zero (workspace contract);
+    // every such workgroup has read ovf_ctl[0] and the list before it counts itself in
+    if (tid == 0) {
+      __threadfence();
+      const int done = atomicAdd(rp.ovf_ctl + 2, 1) + 1;
+      if (done == __hip_atomic_load(rp.ovf_ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        rp.ovf_ctl[0] = 0; rp.ovf_ctl[1] = 0; rp.ovf_ctl[2] = 0;
+      }
+    }
   }
   const bool any = n > 0 || over;  // the tile holds sums
 
@@ -740,6 +800,7 @@ extern "C" int lss_lift_splat_bwd(const void* grad_bev, int layout, const int32_
 // Can the region-bucketed pipeline run this problem out of the ABI's workspace?  (vox_count: the zero-between-
 // calls words; vox_list: plain scratch.)  Otherwise the voxel-list pipeline below is used.
 constexpr int LSS_DIRECT_CAP = 1024;     // slots per region of the direct form (the busiest region of the benched rigs
+constexpr int LSS_DIRECT_OVF = 65536;     // records of the overflow list (16 B each: 1 MiB)
 constexpr int LSS_DIRECT_MIN_CAP = 256;  // holds ~410 points); below this capacity the three-launch form is used instead
 
 static bool region_plan_for(int B, int N, int D, int fH, int fW, int C, int X, int Y, int Z, int32_t* vox_count,
@@ -747,6 +808,9 @@ static bool region_plan_for(int B, int N, int D, int fH, int fW, int C, int X, i
                             unsigned long long direct_bytes = 0) {
   rp->dentries = nullptr;
   rp->cap = 0;
+  rp->ovf = nullptr;
+  rp->ovf_ctl = nullptr;
+  rp->ovf_cap = 0;
   if (const char* e = getenv("LSS_SPLAT_LEGACY"))
     if (atoi(e) != 0) return false;
   const long long nvox = (long long)B * X * Y * Z, P = (long long)B * N * D * fH * fW;
@@ -770,12 +834,20 @@ static bool region_plan_for(int B, int N, int D, int fH, int fW, int C, int X, i
   // the direct form: as many slots per region as the caller's workspace holds, at most LSS_DIRECT_CAP
   if (direct_entries != nullptr && (reinterpret_cast<uintptr_t>(direct_entries) & 7) == 0 &&
       !(getenv("LSS_SPLAT_DIRECT") != nullptr && atoi(getenv("LSS_SPLAT_DIRECT")) == 0)) {
-    long long cap = (long long)(direct_bytes / 8) / nreg;
+    // the overflow list takes the buffer's tail when the buckets leave room for it
+    const unsigned long long ovf_bytes = (unsigned long long)LSS_DIRECT_OVF * 16;
+    const bool with_list = direct_bytes >= (unsigned long long)nreg * LSS_DIRECT_MIN_CAP * 8 + ovf_bytes;
+    long long cap = (long long)((direct_bytes - (with_list ? ovf_bytes : 0)) / 8) / nreg;
     if (cap > LSS_DIRECT_CAP) cap = LSS_DIRECT_CAP;
     cap &= ~7LL;
-    if (cap >= LSS_DIRECT_MIN_CAP && nreg * cap < (1LL << 31)) {
+    if (cap >= LSS_DIRECT_MIN_CAP && nreg * cap < (1LL << 31) && nreg >= 3) {
       rp->dentries = reinterpret_cast<int32_t*>(direct_entries);
       rp->cap = (int)cap;
+      rp->ovf_ctl = rp->region_cursor;   // (three of the zero-between-calls words the direct form does not use)
+      if (with_list) {
+        rp->ovf = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(direct_entries) + (size_t)nreg * cap * 8);
+        rp->ovf_cap = LSS_DIRECT_OVF;
+      }
     }
   }
   return true;
@@ -787,7 +859,7 @@ extern "C" size_t lss_lift_splat_direct_bytes(int B, int N, int D, int fH, int f
   static int32_t dummy[4];
   LssRegionPlan rp;
   if (!region_plan_for(B, N, D, fH, fW, C, X, Y, Z, dummy, dummy, &rp)) return 0;
-  return (size_t)B * rp.rps * LSS_DIRECT_CAP * 8;
+  return (size_t)B * rp.rps * LSS_DIRECT_CAP * 8 + (size_t)LSS_DIRECT_OVF * 16;
 }
 
 // Does lss_lift_splat_forward run this problem on the region-bucketed pipeline (f32 depthnet math assumed)?  The same

@@ -89,6 +89,9 @@ CASES = [
     (1, 2, 41, 8, 22, 64, dict(xbound=[-50.0, 50.0, 25.0], ybound=[-50.0, 50.0, 25.0], zbound=[-10.0, 10.0, 20.0],
                                dbound=[4.0, 45.0, 1.0]), (128, 352), False),     # 4 x 4 cells, one region: thousands of
                                                                                  # points collide in each central cell
+    (1, 6, 60, 16, 44, 64, dict(xbound=[-48.0, 48.0, 4.0], ybound=[-48.0, 48.0, 4.0], zbound=[-10.0, 10.0, 20.0],
+                                dbound=[4.0, 64.0, 1.0]), (256, 704), False),    # hi-res frustum (253 k points) into NINE
+                                                                                 # regions: buckets AND overflow list overflow
 ]
 
 
@@ -233,9 +236,10 @@ def test_direct_form_equals_three_launch_form_bit_for_bit(ops, monkeypatch, case
     per-region buckets, no fill launch, the splat gathers the depth weights - against the three-launch form on the
     same operands: the sums are exact fixed-point integers, so the grids must be EQUAL, bit for bit, whatever order the
     two bucketings produced; the zero-between-calls words are back at zero; and a second call on the same workspace
-    reproduces the first.  CASES[3] (about 900 points in its busiest regions) and CASES[4] (one region holding every
-    point of the sample: far beyond the 1024 slots of its bucket) take the overflow path, which rebuilds such a region
-    from the voxel ids (ref src/model_BEV_TXT.py:84-126: the sums are the same whichever way the points are grouped)."""
+    reproduces the first.  CASES[3] (a coarse grid: thousands of points in its busiest regions) and CASES[4] (one region
+    holding every point of the sample) go beyond the 1024 slots of a bucket: full bucket + the region's records of the
+    overflow list; CASES[5] overflows the list as well and is rebuilt from the voxel ids (ref
+    src/model_BEV_TXT.py:84-126: the sums are the same whichever way the points are grouped)."""
     B, N, D, fH, fW, C, grid, fd, rc = CASES[case]
     pr = problem(B, N, D, fH, fW, C, grid, fd, seed=case, randn_calib=rc)
     X, Y, Z = pr["nx"]
@@ -251,8 +255,21 @@ def test_direct_form_equals_three_launch_form_bit_for_bit(ops, monkeypatch, case
     assert int(ws.vox_count.abs().sum()) == 0 and int(ws.cursor.abs().sum()) == 0
     bev2, *_ = run(ops, pr, layout, False, monkeypatch, ws=ws)
     assert torch.equal(bev2, ref)
-    if case == 4:  # really the overflow path: more points in the one region than a bucket holds
-        assert int((ws.voxel >= 0).sum()) > 1024
+    # which path the over-capacity regions took: excess = points beyond the 1024 slots of their buckets; up to 65 536 of
+    # them sit in the overflow list (full bucket + the region's records), more than that and the regions are rebuilt
+    # from the voxel ids
+    v = ws.voxel[ws.voxel >= 0].long()
+    cxy = v // Z
+    bb, ix, iy = cxy // (X * Y), (cxy % (X * Y)) // Y, cxy % Y
+    nRy = (Y + 7) // 8
+    counts = torch.bincount((bb * ((X + 7) // 8) + ix // 8) * nRy + iy // 8)
+    excess = int((counts - 1024).clamp(min=0).sum())
+    if case in (3, 4):
+        assert 0 < excess <= 65536     # the list path
+    if case == 5:
+        assert excess > 65536          # the rebuild path
+    if case in (0, 1, 2):
+        assert excess == 0
     # the host-calibration entry takes the direct form too
     bev_h, *_ = run(ops, pr, layout, False, monkeypatch, hostcal=True)
     assert torch.equal(bev_h, ref)
