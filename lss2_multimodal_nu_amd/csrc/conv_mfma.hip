@@ -1240,7 +1240,9 @@ extern "C" int lss_conv2d_fwd(const void* x, const void* x2, const void* w_packe
     if (dt != LSS_DT_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || stats != nullptr || C2 != 0 || up != 1 ||
         (relu & ~(LSS_W_KS | 1)) != 0)
       return LSS_E_SHAPE;
-    const bool wt_ks = (getenv("LSS_CONV_WT") == nullptr || atoi(getenv("LSS_CONV_WT")) != 0);
+    // write-back stores here (LSS_KS_WT=1: write-through like the other kernels): 5 MB of output per launch at most,
+    // read back by the next launch - measured in a dependent chain 9.47 / 8.22 / 7.48 -> 9.07 / 8.11 / 7.36 us per launch
+    const bool wt_ks = getenv("LSS_KS_WT") != nullptr && atoi(getenv("LSS_KS_WT")) != 0;
     return lss_conv_ks_launch(x, w_packed, scale, shift, residual, y, B, H, W, Cx, Cout, relu & 1, wt_ks ? 1 : 0,
                               lss_stream(stream));
   }

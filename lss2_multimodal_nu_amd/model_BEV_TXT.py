@@ -340,12 +340,23 @@ class _LiftSplatMixin:
     def get_voxels(self, x, rots, trans, intrins, post_rots, post_trans):
         return self._lift_splat(x, rots, trans, intrins, post_rots, post_trans, ops.BEV_NCHW_F32)
 
+    def _train_voxels(self, x, rots, trans, intrins, post_rots, post_trans):
+        """`get_voxels` for the autograd path.  Under bf16 autocast BevEncode's stem takes its input as bf16 NHWC
+        rows anyway (modules._ConvS2Fn), so the splat writes exactly that (layout NHWC bf16, the inference layout: the
+        fp32 sums rounded once, the same bits `.to(bfloat16)` would give) and hands over the logical NCHW view - the
+        (B, 64, 200, 200) fp32 NCHW grid, its permute copy and its cast (41 MB, two launches, 40 us per step) never
+        exist.  fp32 training and LSS_TRAIN_NATIVE=0: `get_voxels` as it is."""
+        from . import modules
+        if modules._native_training() and self.bevencode.training:
+            return self._lift_splat(x, rots, trans, intrins, post_rots, post_trans, ops.BEV_NHWC_BF16)
+        return self.get_voxels(x, rots, trans, intrins, post_rots, post_trans)
+
     def _bev(self, x, rots, trans, intrins, post_rots, post_trans):
         """get_voxels + bevencode with the BEV grid handed over channels-last (bf16
         when the conv path computes in bf16) - no NCHW fp32 round trip."""
         be = self.bevencode
         if _needs_autograd(be, x) or _needs_autograd(self.camencode, x):
-            return be(self.get_voxels(x, rots, trans, intrins, post_rots, post_trans))
+            return be(self._train_voxels(x, rots, trans, intrins, post_rots, post_trans))
         dt = _PRECISIONS[be.precision or default_precision()]
         layout = ops.BEV_NHWC_BF16 if dt == ops.DT_BF16 else ops.BEV_NHWC_F32
         grid = self._lift_splat(x, rots, trans, intrins, post_rots, post_trans, layout)
@@ -381,7 +392,7 @@ class LSS(_LiftSplatMixin, nn.Module):
         (SURVEY.md 8f-3): the (B, outC, X, Y) logits are never materialised.  Not part of the reference's API: an
         opt-in entry for training loops that only need the loss; `forward` + `SimpleLoss` give the same value."""
         x = self.encoder(x)
-        y = self.bevencode.features(self.get_voxels(x, rots, trans, intrins, post_rots, post_trans))
+        y = self.bevencode.features(self._train_voxels(x, rots, trans, intrins, post_rots, post_trans))
         return head_weighted_cross_entropy(y, self.bevencode.up2[4], binimgs, _bev_class_weights(y.device, class_weights))
 
 
@@ -417,7 +428,7 @@ class BEV_TXT(_LiftSplatMixin, nn.Module):
         differentiable scalar with the BEV head + weighted cross-entropy fused; the TXT heads get the logits of
         their 80 x 88 crop only (detached, as in `forward`).  Opt-in, like `LSS.forward_loss`."""
         x = self.encoder(x)
-        y = self.bevencode.features(self.get_voxels(x, rots, trans, intrins, post_rots, post_trans))
+        y = self.bevencode.features(self._train_voxels(x, rots, trans, intrins, post_rots, post_trans))
         head = self.bevencode.up2[4]
         loss_bev = head_weighted_cross_entropy(y, head, binimgs, _bev_class_weights(y.device))
         with torch.no_grad():

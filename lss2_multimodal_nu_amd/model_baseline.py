@@ -47,7 +47,7 @@ class BEV_TXT(_LiftSplatMixin, nn.Module):
         """`MultiLoss(*self(x, ...), binimgs, act_gt, desc_gt)` with the BEV head + weighted cross-entropy fused
         (see `model_BEV_TXT.BEV_TXT.forward_loss`); the heads' crop logits stay differentiable (ref :283)."""
         x = self.encoder(x)
-        y = self.bevencode.features(self.get_voxels(x, rots, trans, intrins, post_rots, post_trans))
+        y = self.bevencode.features(self._train_voxels(x, rots, trans, intrins, post_rots, post_trans))
         head = self.bevencode.up2[4]
         loss_bev = head_weighted_cross_entropy(y, head, binimgs, _bev_class_weights(y.device))
         bev_post = self.embeder_bev(self.bevpost(head(y[:, :, 60:140, 56:144].float())))

@@ -900,9 +900,14 @@ class BevEncode(nn.Module):
     def features(self, x):
         """Differentiable path up to (not including) the 1x1 head `up2[4]`: (B, inC, X, Y) -> (B, 128, X, Y), the
         activation `tools.head_weighted_cross_entropy` fuses the head and the loss on."""
-        x = x.float() if x.dtype != torch.float32 else x
         if _native_training() and x.is_cuda:
-            x = x.contiguous(memory_format=torch.channels_last)  # the whole chain then stays NHWC
+            # the whole chain stays NHWC; a bf16 NHWC grid (the training splat's, model_BEV_TXT._train_voxels) is what the
+            # stem reads anyway: taken as it is, no fp32 round trip
+            if x.dtype not in (torch.float32, torch.bfloat16):
+                x = x.float()
+            x = x.contiguous(memory_format=torch.channels_last)
+        elif x.dtype != torch.float32:
+            x = x.float()
         outer, _tls.counters = getattr(_tls, "counters", None), []
         try:
             x = _train_bn_act(self.bn1, _train_conv(self.conv1, x), relu=True)
