@@ -416,6 +416,12 @@ int lss_conv_bn_act_train_fwd(const void* x1, const void* x2, const float* w_oih
                               float* running_var, void* w_packed, void* z, void* y, float* save_mean,
                               float* save_invstd, void* bn_workspace, int B, int H, int W, int Cx, int C2,
                               int up, int Cout, float momentum, float eps, int relu, void* stream);
+/* The weight image the unit of this shape runs on (forward: dgrad = 0, input-gradient conv: dgrad = 1): the same
+ * ring / K-split / tile decision the two calls below make.  With it a host packs a layer's images itself and passes
+ * w_oihw = NULL to the units (w_packed / w_dgrad then hold the images) - e.g. all layers of a model in one launch per
+ * step through lss_gather_pack. */
+int lss_conv_bn_act_train_pack(const float* w_oihw, int B, int H, int W, int Cx, int C2, int up, int Cout, int dgrad,
+                               void* w_packed, void* stream);
 int lss_conv_bn_act_train_bwd(const void* dy, const void* y, const void* z, const void* x1, const void* x2,
                               const float* w_oihw, const float* gamma, const float* save_mean,
                               const float* save_invstd, void* bn_workspace, void* wgrad_workspace,
@@ -423,6 +429,15 @@ int lss_conv_bn_act_train_bwd(const void* dy, const void* y, const void* z, cons
                               float* dgamma, float* dbeta, void* gcat, void* g1, void* xcat, float* dw,
                               int B, int H, int W, int Cx, int C2, int up, int Cout, int relu,
                               void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Gather-pack (training): every packed weight image of a step in ONE launch.  A packed image is a permutation of the
+ * layer's fp32 weights (+ zeros): out[e] = idx[e] ? bf16(src[idx[e] - 1]) : 0.  `jobs`: HOST array of `count` records
+ *     { const float* src; const int32_t* idx; uint16_t* dst; long long n; }          (device pointers)
+ * passed on by value in the kernel arguments.  The host derives idx once per layer by pushing index patterns through
+ * that layer's own lss_*_pack_weights* routine (lss2_multimodal_nu_amd/ops.py: WeightPrepack); replaces the 36 pack
+ * launches a training step otherwise needs (the weights change every step; no reference counterpart). */
+int lss_gather_pack(const void* jobs, int count, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K10  gradient-norm clip + Adam over a list of fp32 tensors (training; replaces

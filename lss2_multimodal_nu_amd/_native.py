@@ -52,6 +52,8 @@ SIGNATURES = {
     "lss_conv2d_ks_packed_weight_bytes": (_sz, [_i, _i]),
     "lss_conv2d_pack_weights_ks": (_i, [_vp, _i, _i, _vp, _vp]),
     "lss_conv2d_pack_weights_ks_dgrad": (_i, [_vp, _i, _i, _vp, _vp]),
+    "lss_gather_pack": (_i, [_vp, _i, _vp]),
+    "lss_conv_bn_act_train_pack": (_i, [_vp] + [_i] * 8 + [_vp, _vp]),
     "lss_clip_adam_partials": (ctypes.c_longlong, [_vp, _i]),
     "lss_clip_adam_step": (_i, [_vp, _i, _vp, _vp, ctypes.c_longlong] + [ctypes.c_float] * 6 + [_vp]),
     "lss_conv2d_wgrad_timeouts": (_i, []),

@@ -305,21 +305,53 @@ static bool train_ring_enabled() {
   return e == nullptr || atoi(e) != 0;
 }
 
+// The weight image a training unit of this shape runs on - forward (dgrad = 0) or input-gradient conv (dgrad = 1):
+// ring kernel where the shape qualifies, K-split kernel for the launch-bound layers, tile kernel otherwise.  ONE place
+// decides, for the units below and for lss_conv_bn_act_train_pack (which lets a host pack every layer's images ahead of
+// the step, ops.WeightPrepack).
+static int train_unit_pack(const float* w_oihw, int B, int H, int W, int Cx, int C2, int up, int Cout, int dgrad,
+                           void* w_packed, int* flags, void* stream) {
+  const int Hh = H * up, Wh = W * up, Ct = Cx + C2;
+  bool ring, ks;
+  if (!dgrad) {
+    ring = train_ring_enabled() && lss_conv2d_ring_ok(B, H, W, Cx, C2, up, Cout, 0);
+    ks = !ring && C2 == 0 && up == 1 && lss_conv2d_ks_ok(B, H, W, Cx, Cout);
+  } else {  // the gradient conv: Cout -> Ct channels on the (upsampled) grid
+    ring = train_ring_enabled() && lss_conv2d_ring_ok(B, Hh, Wh, Cout, 0, 1, Ct, 0);
+    ks = !ring && lss_conv2d_ks_ok(B, Hh, Wh, Cout, Ct);
+  }
+  if (flags != nullptr) *flags = (ring ? LSS_W_RING : 0) | (ks ? LSS_W_KS : 0);
+  if (w_oihw == nullptr) return 0;  // the caller packed ahead of the step
+  if (!dgrad)
+    return ring ? lss_conv2d_pack_weights_ring(w_oihw, Cout, Ct, w_packed, stream)
+           : ks ? lss_conv2d_pack_weights_ks(w_oihw, Cout, Cx, w_packed, stream)
+                : lss_conv2d_pack_weights(w_oihw, Cout, Ct, 3, 3, LSS_DT_BF16, w_packed, stream);
+  return ring ? lss_conv2d_pack_weights_ring_dgrad(w_oihw, Cout, Ct, w_packed, stream)
+         : ks ? lss_conv2d_pack_weights_ks_dgrad(w_oihw, Cout, Ct, w_packed, stream)
+              : lss_conv2d_pack_weights_dgrad(w_oihw, Cout, Ct, 3, 3, LSS_DT_BF16, w_packed, stream);
+}
+
+extern "C" int lss_conv_bn_act_train_pack(const float* w_oihw, int B, int H, int W, int Cx, int C2, int up, int Cout,
+                                          int dgrad, void* w_packed, void* stream) {
+  LSS_CHECK_PTR(w_oihw); LSS_CHECK_PTR(w_packed);
+  if (dgrad != 0 && dgrad != 1) return LSS_E_SHAPE;
+  return train_unit_pack(w_oihw, B, H, W, Cx, C2, up, Cout, dgrad, w_packed, nullptr, stream);
+}
+
 extern "C" int lss_conv_bn_act_train_fwd(const void* x1, const void* x2, const float* w_oihw, const float* gamma,
                                          const float* beta, const void* residual, float* running_mean,
                                          float* running_var, void* w_packed, void* z, void* y, float* save_mean,
                                          float* save_invstd, void* bn_workspace, int B, int H, int W, int Cx, int C2,
                                          int up, int Cout, float momentum, float eps, int relu, void* stream) {
-  // the big layers run on the loader / consumer ring kernel (conv_ring.hip), like the inference path
-  const bool ring = train_ring_enabled() && lss_conv2d_ring_ok(B, H, W, Cx, C2, up, Cout, 0);
-  // ... and the launch-bound ones (layer1-3) on the K-split one-pass kernel (conv_ks.hip)
-  const bool ks = !ring && C2 == 0 && up == 1 && lss_conv2d_ks_ok(B, H, W, Cx, Cout);
-  int rc = ring ? lss_conv2d_pack_weights_ring(w_oihw, Cout, Cx + C2, w_packed, stream)
-           : ks ? lss_conv2d_pack_weights_ks(w_oihw, Cout, Cx, w_packed, stream)
-                : lss_conv2d_pack_weights(w_oihw, Cout, Cx + C2, 3, 3, LSS_DT_BF16, w_packed, stream);
+  // the big layers run on the loader / consumer ring kernel (conv_ring.hip), like the inference path, the launch-bound
+  // ones (layer1-3) on the K-split one-pass kernel (conv_ks.hip); w_oihw == NULL: w_packed already holds the image
+  // (lss_conv_bn_act_train_pack, or a gather-pack of the whole model: lss_gather_pack)
+  LSS_CHECK_PTR(w_packed);
+  int wflags = 0;
+  int rc = train_unit_pack(w_oihw, B, H, W, Cx, C2, up, Cout, 0, w_packed, &wflags, stream);
   if (rc != 0) return rc;
   rc = lss_conv2d_fwd(x1, x2, w_packed, nullptr, nullptr, nullptr, z, nullptr, B, H, W, Cx, C2, up, Cout, 3, 3, 1, 1,
-                      LSS_ACT_NONE | (ring ? LSS_W_RING : 0) | (ks ? LSS_W_KS : 0), LSS_DT_BF16, stream);
+                      LSS_ACT_NONE | wflags, LSS_DT_BF16, stream);
   if (rc != 0) return rc;
   const long long M = (long long)B * (H * up) * (W * up);
   return lss_bn_train_fwd(z, residual, M, Cout, gamma, beta, running_mean, running_var, momentum, eps, relu,
@@ -340,14 +372,11 @@ extern "C" int lss_conv_bn_act_train_bwd(const void* dy, const void* y, const vo
   if (rc != 0) return rc;
   if (gcat != nullptr) {  // input gradient(s): dgrad conv over the (concatenated, upsampled) input
     LSS_CHECK_PTR(w_dgrad);
-    const bool ring = train_ring_enabled() && lss_conv2d_ring_ok(B, Hh, Wh, Cout, 0, 1, Ct, 0);
-    const bool ks = !ring && lss_conv2d_ks_ok(B, Hh, Wh, Cout, Ct);
-    rc = ring ? lss_conv2d_pack_weights_ring_dgrad(w_oihw, Cout, Ct, w_dgrad, stream)
-         : ks ? lss_conv2d_pack_weights_ks_dgrad(w_oihw, Cout, Ct, w_dgrad, stream)
-              : lss_conv2d_pack_weights_dgrad(w_oihw, Cout, Ct, 3, 3, LSS_DT_BF16, w_dgrad, stream);
+    int wflags = 0;   // (w_oihw == NULL: w_dgrad was packed ahead of the step)
+    rc = train_unit_pack(w_oihw, B, H, W, Cx, C2, up, Cout, 1, w_dgrad, &wflags, stream);
     if (rc != 0) return rc;
     rc = lss_conv2d_fwd(dz, nullptr, w_dgrad, nullptr, nullptr, nullptr, gcat, nullptr, B, Hh, Wh, Cout, 0, 1, Ct, 3, 3,
-                        1, 1, LSS_ACT_NONE | (ring ? LSS_W_RING : 0) | (ks ? LSS_W_KS : 0), LSS_DT_BF16, stream);
+                        1, 1, LSS_ACT_NONE | wflags, LSS_DT_BF16, stream);
     if (rc != 0) return rc;
     if (g1 != nullptr) {
       rc = lss_upsample_bwd_nhwc(gcat, B, H, W, Cx, Ct, C2, up, g1, stream);

@@ -30,6 +30,8 @@ import os
 
 import torch
 
+from . import ops
+
 
 def shard_range(global_batch, rank, world):
     """Samples [lo, hi) owned by `rank`: the path shards by sample, all cameras of a
@@ -259,8 +261,12 @@ def train_step(model, bucket, opt, loss_fn, inputs, clip=5.0):
     if bucket is None:
         return train_step_local(model, opt, loss_fn, inputs, clip)
     bucket.zero()
-    loss = loss_fn(model(*inputs))
-    loss.backward()
+    ops.prepack.run()   # every registered bf16 weight image of the step in one launch (ops.WeightPrepack)
+    try:
+        loss = loss_fn(model(*inputs))
+        loss.backward()
+    finally:
+        ops.prepack.invalidate()
     bucket.all_reduce_mean()
     _clip_and_step(opt, bucket, None, clip)
     return loss.detach()
@@ -297,8 +303,12 @@ def train_step_local(model, opt, loss_fn, inputs, clip=5.0):
     params = [p for g in opt.param_groups for p in g["params"]]
     for p in params:
         p.grad = None
-    loss = loss_fn(model(*inputs))
-    loss.backward()
+    ops.prepack.run()   # every registered bf16 weight image of the step in one launch (ops.WeightPrepack)
+    try:
+        loss = loss_fn(model(*inputs))
+        loss.backward()
+    finally:
+        ops.prepack.invalidate()
     _clip_and_step(opt, None, params, clip)
     return loss.detach()
 
@@ -372,11 +382,13 @@ class GraphedTrainStep:
                 # (thread-local capture mode: the process group's watchdog thread keeps querying its events meanwhile)
                 with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                     bucket.zero()
+                    ops.prepack.run()
                     loss = loss_fn(model(*self._inputs))
                     loss.backward()
                     self.loss = loss.detach()
             finally:
                 bucket.capturing = False
+                ops.prepack.invalidate()
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, pool=self.graph.pool(), capture_error_mode="thread_local"):
                 _clip_and_step(opt, bucket, None, clip)

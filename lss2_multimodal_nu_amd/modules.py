@@ -195,7 +195,9 @@ def conv_s2_dgrad_phase_planes(gyn, weight, pad, H, W):
     library's transposed-conv kernels are not: the loss of the captured step differed run to run with them)."""
     B, Ho, Wo, Co = gyn.shape
     C = weight.shape[1]
-    wp, KT = ops.pack_conv_weight_s2_dgrad(weight.detach().float().contiguous(), pad)
+    KT = ops.N.lib().lss_conv2d_s2_dgrad_taps(weight.shape[2], pad)
+    wp = ops.prepacked(weight.detach().float().contiguous(), ("s2_dgrad", pad),
+                       lambda w: ops.pack_conv_weight_s2_dgrad(w, pad)[0])
     ys = ops.conv2d_nhwc(gyn, wp, (KT, KT), 1, KT // 2, tag="conv2d_dgrad")   # (B, Ho + 1, Wo + 1, 4 C) for KT = 2, 4
     s = 1 if KT > 1 else 0
     ys = ys[:, s:s + Ho, s:s + Wo].reshape(B, Ho, Wo, 2, 2, C)
@@ -231,7 +233,8 @@ class _ConvS2Fn(torch.autograd.Function):
         xn = xn.contiguous()  # no copy when x is already channels_last bf16
         w32 = weight.detach().float().contiguous()
         K = weight.shape[2]
-        wp = ops.pack_conv_weight_s2d(w32, pad) if K > 1 else ops.pack_conv_weight(w32, ops.DT_BF16)
+        wp = (ops.prepacked(w32, ("s2d", pad), lambda w: ops.pack_conv_weight_s2d(w, pad)) if K > 1 else
+              ops.prepacked(w32, ("tile",), lambda w: ops.pack_conv_weight(w, ops.DT_BF16)))
         y = ops.conv2d_s2_nhwc(xn, wp, K, pad, tag="conv2d_train_fwd")
         ctx.save_for_backward(xn, weight)
         ctx.cfg = (x.dtype, pad)

@@ -4,6 +4,7 @@ Each function validates shapes/dtypes on the host (a mis-shaped operand must
 never reach a kernel), allocates outputs with torch, and enqueues the kernel on
 torch's current HIP stream.  No CPU / eager fallbacks exist here.
 """
+import ctypes
 import os
 
 import torch
@@ -952,6 +953,107 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+class _GatherJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("n", ctypes.c_longlong)]
+
+
+class WeightPrepack:
+    """Every packed weight image of a training step in ONE launch (csrc/layout.hip: lss_gather_pack).
+
+    The weights change every step, so every conv unit packs its bf16 image(s) - tile / ring / K-split / phase-plane
+    layout, forward and input-gradient form - on every call: 36 small launches per step of the benched model.  A packed
+    image is a permutation of the layer's fp32 weights plus zeros, so it can be produced by a table-driven gather that
+    knows nothing about layouts.  A unit REGISTERS its image the first time it packs one (eager warm-up steps): the
+    table comes from pushing the three byte planes of the element numbers 1..n through the unit's own pack routine
+    (values <= 255 are exact in bf16), and is checked once against that routine on the real weights.  From then on
+    `run()` - called by dp.train_step* at the top of a step - fills every registered image with one launch, and the
+    units find theirs through `lookup` instead of packing; `invalidate()` after the optimizer step makes them pack
+    themselves again unless another `run()` comes first, so a caller with its own loop is never handed a stale image.
+    Keys are (weight address, shape, kind): whatever lives at that address is what gets packed.  LSS_PREPACK=0 disables."""
+
+    def __init__(self):
+        self.jobs = {}
+        self.fresh = False
+        self._table = None
+
+    @staticmethod
+    def enabled():
+        return os.environ.get("LSS_PREPACK", "1") != "0"
+
+    @staticmethod
+    def _key(w, kind):
+        return (w.data_ptr(), tuple(w.shape), str(w.device)) + tuple(kind)
+
+    def lookup(self, w, kind):
+        if not self.fresh:
+            return None
+        j = self.jobs.get(self._key(w, kind))
+        return None if j is None else j[2]
+
+    def register(self, w, kind, pack_fn):
+        """pack_fn(fp32 tensor shaped like w) -> the bf16 image (any shape); no-op while a stream capture is active."""
+        if not self.enabled() or not w.is_cuda or w.dtype != torch.float32 or not w.is_contiguous():
+            return
+        if torch.cuda.is_current_stream_capturing() or w.numel() >= (1 << 24):
+            return
+        key = self._key(w, kind)
+        if key in self.jobs:
+            return
+        n = w.numel()
+        num = torch.arange(1, n + 1, device=w.device, dtype=torch.int64).view(w.shape)
+        idx = None
+        for b in range(3):
+            img = pack_fn(((num >> (8 * b)) & 255).float())
+            v = img.reshape(-1).float().to(torch.int64) << (8 * b)
+            idx = v if idx is None else idx | v
+        ref = pack_fn(w.detach())
+        dst = torch.empty_like(ref)
+        got = torch.where(idx > 0, w.detach().reshape(-1)[(idx - 1).clamp(min=0)], torch.zeros((), device=w.device))
+        if not torch.equal(got.to(torch.bfloat16), ref.reshape(-1)):
+            raise N.LssNativeError("WeightPrepack: the image of kind %s is not a permutation of its weights" % (kind,))
+        self.jobs[key] = (w.data_ptr(), idx.to(torch.int32).contiguous(), dst)
+        self._table = None
+
+    def run(self):
+        """Fill every registered image from the current weights (one launch per 96 images)."""
+        if not self.jobs or not self.enabled():
+            return
+        if self._table is None:
+            tab = (_GatherJob * len(self.jobs))()
+            for i, (src, idx, dst) in enumerate(self.jobs.values()):
+                tab[i].src, tab[i].idx, tab[i].dst, tab[i].n = src, idx.data_ptr(), dst.data_ptr(), idx.numel()
+            self._table = tab
+        N.check(N.lib().lss_gather_pack(ctypes.cast(self._table, ctypes.c_void_p), len(self.jobs), N.stream()),
+                "lss_gather_pack")
+        self.fresh = True
+
+    def invalidate(self):
+        self.fresh = False
+
+
+prepack = WeightPrepack()
+
+
+def prepacked(w, kind, pack_fn):
+    """The bf16 image of weights `w` a unit needs: the step's pre-packed one when `prepack.run()` has filled it,
+    else packed now (and registered for the next steps)."""
+    pk = prepack.lookup(w, kind)
+    if pk is not None:
+        return pk
+    out = pack_fn(w)
+    prepack.register(w, kind, pack_fn)
+    return out
+
+
+def _unit_pack_fn(B, H, W, Cx, C2, up, Cout, dgrad):
+    def fn(w):
+        out = torch.empty(9 * Cout * (Cx + C2), dtype=torch.bfloat16, device=w.device)
+        N.check(N.lib().lss_conv_bn_act_train_pack(w.data_ptr(), B, H, W, Cx, C2, up, Cout, dgrad, out.data_ptr(),
+                                                   N.stream()), "lss_conv_bn_act_train_pack")
+        return out
+    return fn
+
+
 def conv_bn_act_train_fwd(x1n, x2n, weight, gamma, beta, resn, running_mean, running_var, momentum, eps, relu, up):
     """One host call: conv3x3 (fused upsample/concat input) -> BN(train) -> (+res) -> ReLU.  Operands are
     trusted (contiguous bf16 NHWC activations, fp32 parameters): the caller is modules._ConvBNActFn.
@@ -962,12 +1064,18 @@ def conv_bn_act_train_fwd(x1n, x2n, weight, gamma, beta, resn, running_mean, run
     dev = x1n.device
     z = torch.empty(B, H * up, W * up, Cout, dtype=torch.bfloat16, device=dev)
     y = torch.empty_like(z)
-    wp = torch.empty(9 * Cout * (Cx + C2), dtype=torch.bfloat16, device=dev)
+    kind = ("unit", 0, B, H, W, Cx, C2, up)
+    wp = prepack.lookup(weight, kind)          # filled by prepack.run() at the top of the step, or ...
+    wsrc = None
+    if wp is None:                             # ... packed inside the call (and registered for the next steps)
+        wp = torch.empty(9 * Cout * (Cx + C2), dtype=torch.bfloat16, device=dev)
+        wsrc = weight
+        prepack.register(weight, kind, _unit_pack_fn(B, H, W, Cx, C2, up, Cout, 0))
     stat = torch.empty(2, Cout, dtype=torch.float32, device=dev)
     ws = _bn_workspace(B * H * up * W * up, Cout, dev)
     with _timed("conv_bn_act_train_fwd"):
         N.check(N.lib().lss_conv_bn_act_train_fwd(
-            x1n.data_ptr(), _p(x2n), weight.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(resn), _p(running_mean),
+            x1n.data_ptr(), _p(x2n), _p(wsrc), gamma.data_ptr(), beta.data_ptr(), _p(resn), _p(running_mean),
             _p(running_var), wp.data_ptr(), z.data_ptr(), y.data_ptr(), stat.data_ptr(), stat.data_ptr() + 4 * Cout,
             ws.data_ptr(), B, H, W, Cx, C2, up, Cout, momentum, eps, 1 if relu else 0, N.stream()),
             "lss_conv_bn_act_train_fwd")
@@ -985,11 +1093,16 @@ def conv_bn_act_train_bwd(gyn, y, z, x1n, x2n, weight, gamma, stat, relu, up, wa
     dres = torch.empty_like(z) if want_res else None
     dgb = torch.empty(2, Cout, dtype=torch.float32, device=dev)
     plain = up == 1 and C2 == 0
-    gcat = g1 = xcat = gw = wd = wws = None
+    gcat = g1 = xcat = gw = wd = wws = wsrc = None   # wsrc: the fp32 weights, when the call has to pack the dgrad image
     nws = 0
     if want_x1 or want_x2:
         gcat = torch.empty(B, Hh, Wh, Ct, dtype=torch.bfloat16, device=dev)
-        wd = torch.empty(9 * Cout * Ct, dtype=torch.bfloat16, device=dev)
+        kind = ("unit", 1, B, H, W, Cx, C2, up)
+        wd = prepack.lookup(weight, kind)
+        if wd is None:
+            wd = torch.empty(9 * Cout * Ct, dtype=torch.bfloat16, device=dev)
+            wsrc = weight
+            prepack.register(weight, kind, _unit_pack_fn(B, H, W, Cx, C2, up, Cout, 1))
         if want_x1 and not plain:
             g1 = torch.empty(B, H, W, Cx, dtype=torch.bfloat16, device=dev)
     if want_w:
@@ -1004,7 +1117,7 @@ def conv_bn_act_train_bwd(gyn, y, z, x1n, x2n, weight, gamma, stat, relu, up, wa
     ws = _bn_workspace(B * Hh * Wh, Cout, dev)
     with _timed("conv_bn_act_train_bwd"):
         N.check(N.lib().lss_conv_bn_act_train_bwd(
-            gyn.data_ptr(), y.data_ptr(), z.data_ptr(), x1n.data_ptr(), _p(x2n), weight.data_ptr(), gamma.data_ptr(),
+            gyn.data_ptr(), y.data_ptr(), z.data_ptr(), x1n.data_ptr(), _p(x2n), _p(wsrc), gamma.data_ptr(),
             stat.data_ptr(), stat.data_ptr() + 4 * Cout, ws.data_ptr(), _p(wws), nws, _p(wd), dz.data_ptr(), _p(dres),
             dgb.data_ptr(), dgb.data_ptr() + 4 * Cout, _p(gcat), _p(g1), _p(xcat), _p(gw), B, H, W, Cx, C2, up, Cout,
             1 if relu else 0, N.stream()), "lss_conv_bn_act_train_bwd")

@@ -308,3 +308,42 @@ def test_wgrad4x4_odd_geometries():
         err = float((dw.cpu() - ref).abs().max()) / float(ref.abs().max())
         assert err <= 2e-4, ((B, H, W, Cin, Cout), err)
     assert ops.N.lib().lss_conv2d_wgrad_timeouts() == 0
+
+
+def test_prepacked_weight_images_equal_per_unit_packs(monkeypatch):
+    """ops.WeightPrepack (every packed weight image of a step from ONE table-driven gather launch, csrc/layout.hip)
+    against the units packing their own images: three training steps of BevEncode through dp.train_step_local with the
+    switch off and on leave bit-identical losses, gradients and parameters; with it on every conv unit registered its
+    forward and input-gradient images (tile, ring, K-split and phase-plane layouts are all among them at this shape)."""
+    import lss2_multimodal_nu_amd as L
+    from lss2_multimodal_nu_amd import dp
+
+    def run(on):
+        monkeypatch.setenv("LSS_PREPACK", "1" if on else "0")
+        ops.prepack.jobs.clear()
+        ops.prepack._table = None
+        torch.manual_seed(11)
+        be = L.BevEncode(64, 4).cuda().train()
+        opt = L.ClipAdam(be.parameters(), lr=1e-3, weight_decay=1e-7)
+        g = torch.Generator().manual_seed(4)
+        x = torch.randn(4, 64, 200, 200, generator=g).cuda()
+        tgt = torch.randn(4, 4, 200, 200, generator=g).cuda()
+
+        def model(inp):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return be(inp)
+        out = []
+        for _ in range(3):
+            loss = dp.train_step_local(model, opt, lambda y: ((y.float() - tgt) ** 2).mean(), (x,), clip=5.0)
+            torch.cuda.synchronize()
+            out.append((float(loss), [p.grad.detach().clone() for p in be.parameters()],
+                        [p.detach().clone() for p in be.parameters()]))
+        return out, len(ops.prepack.jobs)
+
+    (a, na), (b, nb) = run(False), run(True)
+    assert na == 0 and nb >= 30   # 13 3x3 units x 2 images + the five stride-2 convs' forward and gradient images
+    for (la, ga, pa), (lb, gb, pb) in zip(a, b):
+        assert la == lb
+        assert all(torch.equal(u, v) for u, v in zip(ga, gb))
+        assert all(torch.equal(u, v) for u, v in zip(pa, pb))
+    assert not ops.prepack.fresh   # a step leaves the images marked stale: nobody is handed last step's weights
