@@ -201,7 +201,7 @@ int lss_lift_splat_fwd(const float* feat, const int32_t* vox_list, const int32_t
  * K7  backward of K5/K6 (+ softmax backward), point-stationary gather, no atomics.
  * replaces: src/tools.py:211-218 (QuickCumsum.backward) + the autograd nodes of
  *           src/model_BEV_TXT.py:80-121 and src/modules.py:83-84.
- *   grad_bev   BEV gradient in `layout` (NCHW_F32 or NHWC_F32)
+ *   grad_bev   BEV gradient in `layout` (NCHW_F32, NHWC_F32, or NHWC_BF16: the gradient a bf16 stem hands back)
  *   voxel      (P) int32 from K3
  *   g_logits   (BN, D+C, HW) fp32 out: gradient w.r.t. the depthnet output
  *              (softmax backward applied to the first D channels)

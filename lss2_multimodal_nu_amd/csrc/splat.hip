@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256) void region_splat_kernel(const float* __restri
 //   g_logit[d] = depth[d] * (g_depth[d] - sum_d' depth[d'] g_depth[d'])   (softmax bwd)
 // Dropped points (voxel < 0) contribute nothing (ref: x[kept], src/model_BEV_TXT.py:103).
 template <int CPL, int LAYOUT>
-__global__ __launch_bounds__(256) void lift_splat_bwd_kernel(
+__global__ __launch_bounds__(1024) void lift_splat_bwd_kernel(
     const float* __restrict__ G, const int32_t* __restrict__ voxel,
     const float* __restrict__ depth, const float* __restrict__ feat, int D, int HW, int XY, int Z,
     float* __restrict__ g_logits) {
@@ -665,8 +665,10 @@ __global__ __launch_bounds__(256) void lift_splat_bwd_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bn = blockIdx.y, pix0 = blockIdx.x * PIXW;
   const int ZC = Z * C;
-  for (int i = 0; i < 4; ++i) {
-    const int pl = wave * 4 + i;  // pixel slot in the workgroup
+  // one pixel per wave, sixteen waves per workgroup (four per SIMD: three more to hide each gather's round trip than the
+  // four-pixels-per-wave form had)
+  for (int i = 0; i < 1; ++i) {
+    const int pl = wave;  // pixel slot in the workgroup
     const int pix = pix0 + pl;
     if (pix >= HW) break;  // wave-uniform
     float f[CPL], gf[CPL];
@@ -687,26 +689,43 @@ __global__ __launch_bounds__(256) void lift_splat_bwd_kernel(
         dv = depth[p];
       }
       float gd_mine = 0.f;
-      for (int d = 0; d < nd; ++d) {
-        const int v = __builtin_amdgcn_readlane(vv, d);
-        if (v < 0) continue;  // wave-uniform
-        const float dep = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv), d));
-        float part = 0.f;
+      // The gradient rows of EIGHT points are requested before any of them is used (dropped points read row 0 and are
+      // skipped afterwards): with one load in flight per wave and one wave per SIMD - 264 workgroups - the kernel was a
+      // chain of 164 dependent L2 round trips per wave: 87 us of the training step (round 4: see DESIGN.md section 9).
+      for (int d = 0; d < nd; d += 8) {
+        int vs[8];
+        float g[8][CPL];
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-          float g;
-          if (LAYOUT == LSS_BEV_NCHW_F32) {
-            const int cell = v / Z, iz = v % Z;       // v = (b*XY + c)*Z + iz
-            const int bb = cell / XY, cc = cell % XY;
-            g = G[((size_t)bb * ZC + iz * C + q * 64 + lane) * XY + cc];
-          } else {
-            g = G[(size_t)v * C + q * 64 + lane];
+        for (int u = 0; u < 8; ++u) {
+          const int v = __builtin_amdgcn_readlane(vv, min(d + u, nd - 1));
+          vs[u] = d + u < nd ? v : -1;
+          const int vr = v < 0 ? 0 : v;  // a valid row for the loads of points that do not count
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) {
+            if (LAYOUT == LSS_BEV_NCHW_F32) {
+              const int cell = vr / Z, iz = vr % Z;       // v = (b*XY + c)*Z + iz
+              const int bb = cell / XY, cc = cell % XY;
+              g[u][q] = G[((size_t)bb * ZC + iz * C + q * 64 + lane) * XY + cc];
+            } else if (LAYOUT == LSS_BEV_NHWC_BF16) {
+              g[u][q] = lss_bf2f(reinterpret_cast<const unsigned short*>(G)[(size_t)vr * C + q * 64 + lane]);
+            } else {
+              g[u][q] = G[(size_t)vr * C + q * 64 + lane];
+            }
           }
-          gf[q] = fmaf(dep, g, gf[q]);
-          part = fmaf(f[q], g, part);
         }
-        part = lss_wave_sum(part);
-        if (lane == d) gd_mine = part;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (vs[u] < 0) continue;  // wave-uniform
+          const float dep = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv), d + u));
+          float part = 0.f;
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) {
+            gf[q] = fmaf(dep, g[u][q], gf[q]);
+            part = fmaf(f[q], g[u][q], part);
+          }
+          part = lss_wave_sum(part);
+          if (lane == d + u) gd_mine = part;
+        }
       }
       dot_acc += lss_wave_sum(dv * gd_mine);
       // stash (depth, g_depth) of this chunk for the second softmax-backward pass
@@ -727,7 +746,7 @@ __global__ __launch_bounds__(256) void lift_splat_bwd_kernel(
   }
   __syncthreads();
   const int NO = D + C;
-  for (int e = tid; e < NO * PIXW; e += 256) {
+  for (int e = tid; e < NO * PIXW; e += 1024) {
     const int n = e / PIXW, pl = e % PIXW;
     if (pix0 + pl < HW) g_logits[((size_t)bn * NO + n) * HW + pix0 + pl] = lds[n * (PIXW + 1) + pl];
   }
@@ -775,7 +794,7 @@ extern "C" int lss_lift_splat_bwd(const void* grad_bev, int layout, const int32_
   LSS_CHECK_POS(B); LSS_CHECK_POS(N); LSS_CHECK_POS(D); LSS_CHECK_POS(fH); LSS_CHECK_POS(fW);
   LSS_CHECK_POS(X); LSS_CHECK_POS(Y); LSS_CHECK_POS(Z);
   if (C != 64 && C != 128) return LSS_E_SHAPE;
-  if (layout != LSS_BEV_NCHW_F32 && layout != LSS_BEV_NHWC_F32) return LSS_E_LAYOUT;
+  if (layout != LSS_BEV_NCHW_F32 && layout != LSS_BEV_NHWC_F32 && layout != LSS_BEV_NHWC_BF16) return LSS_E_LAYOUT;
   if ((long long)B * N > 65535) return LSS_E_SHAPE;
   const int HW = fH * fW, XY = X * Y;
   const size_t lds_bytes = (size_t)(D + C) * 17 * sizeof(float);
@@ -784,14 +803,16 @@ extern "C" int lss_lift_splat_bwd(const void* grad_bev, int layout, const int32_
   hipStream_t st = lss_stream(stream);
   const float* G = reinterpret_cast<const float*>(grad_bev);
 #define LSS_BWD(CPL, LAY)                                                                       \
-  hipLaunchKernelGGL((lift_splat_bwd_kernel<CPL, LAY>), grid, dim3(256), lds_bytes, st, G,      \
+  hipLaunchKernelGGL((lift_splat_bwd_kernel<CPL, LAY>), grid, dim3(1024), lds_bytes, st, G,     \
                      voxel, depth, feat, D, HW, XY, Z, g_logits)
   if (C == 64) {
     if (layout == LSS_BEV_NCHW_F32) LSS_BWD(1, LSS_BEV_NCHW_F32);
-    else LSS_BWD(1, LSS_BEV_NHWC_F32);
+    else if (layout == LSS_BEV_NHWC_F32) LSS_BWD(1, LSS_BEV_NHWC_F32);
+    else LSS_BWD(1, LSS_BEV_NHWC_BF16);
   } else {
     if (layout == LSS_BEV_NCHW_F32) LSS_BWD(2, LSS_BEV_NCHW_F32);
-    else LSS_BWD(2, LSS_BEV_NHWC_F32);
+    else if (layout == LSS_BEV_NHWC_F32) LSS_BWD(2, LSS_BEV_NHWC_F32);
+    else LSS_BWD(2, LSS_BEV_NHWC_BF16);
   }
 #undef LSS_BWD
   return lss_launch_status();

@@ -83,7 +83,7 @@ class _LiftSplatFn(torch.autograd.Function):
     def backward(ctx, grad_bev):
         x, weight, depth, feat, voxel = ctx.saved_tensors
         B, N, D, fH, fW, C = ctx.dims
-        g_logits = ops.lift_splat_bwd(grad_bev.float(), voxel, depth, feat, ctx.dims, ctx.nx)
+        g_logits = ops.lift_splat_bwd(grad_bev, voxel, depth, feat, ctx.dims, ctx.nx)   # (casts only what it must)
         gl = g_logits.view(B * N, D + C, fH * fW)
         xf = x.reshape(B * N, -1, fH * fW)
         w2 = weight.reshape(D + C, -1)

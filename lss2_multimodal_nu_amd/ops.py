@@ -534,19 +534,24 @@ def lift_splat_forward_hostcal(frustum, calib_host, dx, bx, x, weight, bias, ws,
 
 
 def lift_splat_bwd(grad_bev, voxel, depth, feat, dims, nx):
-    """K7.  grad_bev logical (B, Z*C, X, Y), contiguous or channels_last fp32.
-    Returns g_logits (BN, D+C, fH, fW)."""
+    """K7.  grad_bev logical (B, Z*C, X, Y): fp32 contiguous or channels_last, or bf16 channels_last (the gradient a
+    bf16 stem hands back: read as it is, no fp32 copy).  Returns g_logits (BN, D+C, fH, fW)."""
     B, Ncam, D, fH, fW, C = dims
     X, Y, Z = nx
-    if grad_bev.dtype != torch.float32 or tuple(grad_bev.shape) != (B, Z * C, X, Y):
-        raise ValueError("grad_bev must be fp32 (B, Z*C, X, Y)")
-    if grad_bev.is_contiguous():
-        layout = BEV_NCHW_F32
-    elif grad_bev.is_contiguous(memory_format=torch.channels_last):
-        layout = BEV_NHWC_F32
+    if tuple(grad_bev.shape) != (B, Z * C, X, Y):
+        raise ValueError("grad_bev must be (B, Z*C, X, Y)")
+    if grad_bev.dtype == torch.bfloat16 and grad_bev.is_contiguous(memory_format=torch.channels_last):
+        layout = BEV_NHWC_BF16
     else:
-        grad_bev = grad_bev.contiguous()
-        layout = BEV_NCHW_F32
+        if grad_bev.dtype != torch.float32:
+            grad_bev = grad_bev.float()
+        if grad_bev.is_contiguous():
+            layout = BEV_NCHW_F32
+        elif grad_bev.is_contiguous(memory_format=torch.channels_last):
+            layout = BEV_NHWC_F32
+        else:
+            grad_bev = grad_bev.contiguous()
+            layout = BEV_NCHW_F32
     g_logits = torch.empty(B * Ncam, D + C, fH, fW, dtype=torch.float32, device=grad_bev.device)
     N.check(N.lib().lss_lift_splat_bwd(N.ptr(grad_bev), layout, N.ptr(voxel), N.ptr(depth), N.ptr(feat),
                                        B, Ncam, D, fH, fW, C, X, Y, Z, N.ptr(g_logits), N.stream()),

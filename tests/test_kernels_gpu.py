@@ -304,6 +304,11 @@ def test_k5_k7_other_configs_vs_fp64(ops, cfg):
     g_logit_d = dep * (g_dep - (dep * g_dep).sum(1, keepdims=True))
     ref = np.concatenate([g_logit_d, g_feat.transpose(0, 2, 1)], 1).reshape(B * N, D + C, fH, fW)
     np.testing.assert_allclose(g_logits.numpy(), ref, rtol=2e-4, atol=2e-5 * np.abs(ref).max())
+    # the bf16 channels-last gradient a bf16 stem hands back is read as it is: the same numbers as its fp32 copy
+    Gb = G.cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    g16 = ops.lift_splat_bwd(Gb, ws.voxel, depth, feat, dims, (X, Y, Z))
+    g32 = ops.lift_splat_bwd(Gb.float(), ws.voxel, depth, feat, dims, (X, Y, Z))
+    assert torch.equal(g16, g32)
 
 
 def test_segmented_sum(ops, golden):

@@ -615,6 +615,14 @@ def test_forward_loss_fp32_equals_forward_plus_simple_loss(report):
     calib = lo.synthetic_rig(B, train_aug=True, seed=5)
     x = torch.randn(B * 6, 512, 8, 22).cuda()
     tgt = torch.randint(0, 4, (B, 200, 200)).cuda()
+    # one throw-away step first: the library's fp32 convolutions pick their algorithm on the first call of a shape in a
+    # process, and the pick for the first model can differ from what the second one then gets from the cache (seen once
+    # in a differently ordered run: loss 8e-8 apart, gradients 3e-3) - that is the library's, not what is compared here
+    L.SimpleLoss().cuda()(m2(x, *calib), tgt).backward()
+    m2.zero_grad(set_to_none=True)
+    for bn_a, bn_b in zip(m.modules(), m2.modules()):   # (the warm-up moved m2's running statistics: put them back)
+        if isinstance(bn_a, torch.nn.BatchNorm2d):
+            bn_b.load_state_dict(bn_a.state_dict())
     fused = m.forward_loss(x, *calib, tgt)
     two = L.SimpleLoss().cuda()(m2(x, *calib), tgt)
     assert report("forward_loss fp32: |loss diff| / loss", abs(float(fused) - float(two)) / abs(float(two))) <= 1e-5
