@@ -16,6 +16,8 @@
 //        column shift is materialised and the row shift is not.  The GEMM is linear_mfma.hip's
 //        kernel in split-K mode (grid.y = split x tap, fp32 partial tiles), followed by a
 //        fixed-order reduction over the splits (bit-reproducible; no atomics).
+#include <stdlib.h>
+
 #include "lss_common.h"
 
 int lss_wgrad_gemm_launch(const void* dyt, const void* const xt[3], float* partial, int M, int N,
@@ -284,6 +286,61 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const unsigned short*
   }
 }
 
+// The same sums in the same order with the loads of one high-res ROW of the window requested together: the form above
+// walks its (2 up + 1)^2 candidates one dependent 16-B load at a time behind two data-dependent `continue`s - 38.7 us
+// per launch at one wave per SIMD for the x4 layer (round 4; the K7 pattern).  NW >= columns of any window (host-checked).
+template <int NW>
+__global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(const unsigned short* __restrict__ g, int B, int H,
+                                                                int W, int Cx, int Ct, int c_off, int up, float ry,
+                                                                float rx, unsigned short* __restrict__ dx) {
+  const int Hh = H * up, Wh = W * up, P8 = Cx / 8;
+  const long long n = (long long)B * H * W * P8;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int p8 = (int)(e % P8);
+    const long long pix = e / P8;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+    const int Ylo = max(0, (int)floorf((float)(y - 1) / ry)), Yhi = min(Hh - 1, (int)ceilf((float)(y + 1) / ry));
+    const int Xlo = max(0, (int)floorf((float)(x - 1) / rx)), Xhi = min(Wh - 1, (int)ceilf((float)(x + 1) / rx));
+    float wxv[NW];
+    int xoff[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int X = Xlo + i;
+      const float sx = rx * (float)X;
+      const int x0 = (int)sx;
+      const float lx = sx - (float)x0;
+      const float wx = x0 == x ? 1.f - lx : ((x0 + 1 == x && x0 < W - 1) ? lx : 0.f);
+      wxv[i] = X <= Xhi ? wx : 0.f;
+      xoff[i] = min(X, Wh - 1) * Ct;
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int Y = Ylo; Y <= Yhi; ++Y) {
+      const float sy = ry * (float)Y;
+      const int y0 = (int)sy;
+      const float ly = sy - (float)y0;
+      const float wy = y0 == y ? 1.f - ly : ((y0 + 1 == y && y0 < H - 1) ? ly : 0.f);
+      if (wy == 0.f) continue;
+      const unsigned short* row = g + (((size_t)b * Hh + Y) * Wh) * Ct + c_off + p8 * 8;
+      uint4 r[NW];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        r[i] = make_uint4(0, 0, 0, 0);
+        if (wxv[i] != 0.f) r[i] = *reinterpret_cast<const uint4*>(row + xoff[i]);  // (predicated, still one batch)
+      }
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        if (wxv[i] == 0.f) continue;
+        float v[8];
+        unpack8(r[i], v);
+        const float wgt = wy * wxv[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = fmaf(wgt, v[k], acc[k]);
+      }
+    }
+    *reinterpret_cast<uint4*>(dx + (size_t)pix * Cx + p8 * 8) = pack8(acc);
+  }
+}
+
 }  // namespace
 
 extern "C" int lss_conv2d_pack_weights_dgrad(const float* w_oihw, int Cout, int Cin, int KH, int KW, int dt,
@@ -428,8 +485,15 @@ extern "C" int lss_upsample_bwd_nhwc(const void* g, int B, int H, int W, int Cx,
   if (H < 2 || W < 2) return LSS_E_SHAPE;  // ry, rx > 0 below
   const long long n = (long long)B * H * W * (Cx / 8);
   const int grid = (int)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid), dim3(256), 0, lss_stream(stream),
-                     static_cast<const unsigned short*>(g), B, H, W, Cx, Ct, c_off, up, ry, rx,
-                     static_cast<unsigned short*>(dx));
+  // columns a window can span: candidates floor((x - 1) / rx) .. ceil((x + 1) / rx)
+  const int span = (int)ceilf(2.f / rx) + 3;
+  const bool rows_form = getenv("LSS_UPSAMPLE_BWD_ROWS") == nullptr || atoi(getenv("LSS_UPSAMPLE_BWD_ROWS")) != 0;
+#define LSS_UB(KERNEL)                                                                                      \
+  hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), 0, lss_stream(stream), static_cast<const unsigned short*>(g), B, H, \
+                     W, Cx, Ct, c_off, up, ry, rx, static_cast<unsigned short*>(dx))
+  if (rows_form && span <= 8) LSS_UB(upsample_bwd_rows_kernel<8>);
+  else if (rows_form && span <= 12) LSS_UB(upsample_bwd_rows_kernel<12>);
+  else LSS_UB(upsample_bwd_kernel);
+#undef LSS_UB
   return lss_launch_status();
 }

@@ -167,6 +167,22 @@ def test_upsample_cat_and_adjoint_vs_torch(up, C2):
     assert float((dx.float().cpu() - ref_dx).abs().max()) <= 1e-2 * float(ref_dx.abs().max())
 
 
+@pytest.mark.parametrize("cfg", [(2, 25, 25, 256, 64, 4), (2, 100, 100, 256, 0, 2), (1, 7, 9, 64, 64, 4), (1, 5, 6, 64, 0, 3)])
+def test_upsample_adjoint_row_batched_form_equals_the_walk(monkeypatch, cfg):
+    """The row-batched upsample adjoint (the loads of one high-res row of the window requested together) against the
+    candidate-by-candidate walk it replaced (LSS_UPSAMPLE_BWD_ROWS=0): the same sums in the same order, so equal bit
+    for bit - at the two benched shapes (x4 from 25^2 with a skip tensor, x2 from 100^2) and at small odd ones (x3
+    takes the 12-column window)."""
+    B, H, W, Cx, C2, up = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    gcat = torch.randn(B, H * up, W * up, C2 + Cx, generator=g).bfloat16().cuda()
+    monkeypatch.setenv("LSS_UPSAMPLE_BWD_ROWS", "0")
+    ref = ops.upsample_bwd_nhwc(gcat, C2, Cx, up)
+    monkeypatch.delenv("LSS_UPSAMPLE_BWD_ROWS")
+    out = ops.upsample_bwd_nhwc(gcat, C2, Cx, up)
+    assert torch.equal(out, ref) and float(ref.float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("C,relu,res", [(64, True, False), (128, True, True), (256, False, False), (64, False, True)])
 def test_bn_train_fwd_bwd_vs_torch(C, relu, res):
     g = torch.Generator().manual_seed(C + relu + 2 * res)
