@@ -89,8 +89,10 @@ class _LiftSplatFn(torch.autograd.Function):
         w2 = weight.reshape(D + C, -1)
         # the two plain GEMMs of the 1x1-conv backward go to the BLAS library
         gx = torch.matmul(w2.t().unsqueeze(0), gl).view_as(x) if ctx.needs_input_grad[0] else None
-        gw = torch.einsum("bnp,bkp->nk", gl, xf).view_as(weight) if ctx.needs_input_grad[1] else None
-        gb = gl.sum((0, 2)) if ctx.needs_input_grad[2] else None
+        # (one batched GEMM per image + a sum over the images, and two one-axis sums: the einsum / two-axis forms of the
+        # same contractions cost two transposing copies and a strided reduction more - 38 + 9.5 against 21 + 6.4 us)
+        gw = torch.bmm(gl, xf.transpose(1, 2)).sum(0).view_as(weight) if ctx.needs_input_grad[1] else None
+        gb = gl.sum(2).sum(0) if ctx.needs_input_grad[2] else None
         return gx, gw, gb, None, None, None, None, None, None, None
 
 
