@@ -179,18 +179,25 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
     const size_t t = e / Cin;
     const int co = t % Cout;
     const int tap = t / Cout;
-    // four interleaved partial sums (fixed assignment split k -> accumulator k & 3, fixed final
-    // tree): the loads of a thread are independent, so they pipeline instead of serialising
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    // sixteen interleaved partial sums (fixed assignment split k -> accumulator k & 15, fixed final tree): the loads of
+    // a thread are independent, so they pipeline instead of serialising.  (Four accumulators until round 4: layer1's
+    // 36 864 elements x 136 splits are 144 workgroups at one wave per SIMD - 34 dependent round trips, 11.6 us for 20 MB.)
+    float s[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = 0.f;
     int k = 0;
-    for (; k + 4 <= nsplit; k += 4) {
-      s0 += partial[(size_t)k * n + e];
-      s1 += partial[(size_t)(k + 1) * n + e];
-      s2 += partial[(size_t)(k + 2) * n + e];
-      s3 += partial[(size_t)(k + 3) * n + e];
+    for (; k + 16 <= nsplit; k += 16) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] += partial[(size_t)(k + i) * n + e];
     }
-    for (; k < nsplit; ++k) s0 += partial[(size_t)k * n + e];
-    dw[((size_t)co * Cin + ci) * ntap + tap] = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int i = 0; i < 15; ++i)
+      if (k + i < nsplit) s[i] += partial[(size_t)(k + i) * n + e];
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+      for (int i = 0; i < w; ++i) s[i] += s[i + w];
+    dw[((size_t)co * Cin + ci) * ntap + tap] = s[0];
   }
 }
 
