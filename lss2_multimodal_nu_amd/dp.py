@@ -149,6 +149,13 @@ class GradBucket:
         bucket is launched here, in bucket order, then waited for; grads <- mean over ranks."""
         world = self._world()
         if world > 1:
+            import torch.distributed as dist
+            if self._direct is None and self.flat.is_cuda and dist.get_backend(self.group) == "gloo":
+                # a host-driven collective (the one-GPU rehearsal: bench.py under LSS_BENCH_REHEARSE, the gloo tests)
+                # reads the bucket through the host anyway; handing it a buffer whose producing graph is still in the
+                # queue made each step stall 0.8-2.9 s at random with two ranks on one GPU (14 ms with this wait).  RCCL
+                # collectives are stream-ordered on the device and are launched without any host wait.
+                torch.cuda.current_stream().synchronize()
             self._work = []
             for b in range(len(self.buckets)):
                 self._launch(b)
@@ -396,6 +403,15 @@ class GraphedTrainStep:
         self._self_check()
 
     def _replay(self):
+        if os.environ.get("LSS_GRAPH_DEBUG") and self.graph_b is not None:   # per-phase host times (synchronising)
+            import time
+            t = [time.perf_counter()]
+            self.graph.replay(); torch.cuda.synchronize(); t.append(time.perf_counter())
+            self.bucket.all_reduce_all(); torch.cuda.synchronize(); t.append(time.perf_counter())
+            self.graph_b.replay(); torch.cuda.synchronize(); t.append(time.perf_counter())
+            print("    graph A %.2f ms | all-reduce %.2f ms | graph B %.2f ms" % tuple((b - a) * 1e3 for a, b in zip(t, t[1:])),
+                  flush=True)
+            return
         self.graph.replay()
         if self.graph_b is not None:
             self.bucket.all_reduce_all()
@@ -427,6 +443,11 @@ class GraphedTrainStep:
         """One step on new inputs; returns the (static) loss tensor.  `refresh`: (static_tensor, new_value) pairs
         of anything else the captured step reads (e.g. the target tensor of the loss function)."""
         from .data import CalibrationPack
+        dbg = os.environ.get("LSS_GRAPH_DEBUG")
+        if dbg:
+            import time
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
         if feats is not self.feats:
             self.feats.copy_(feats, non_blocking=True)
         if calib is not None:
@@ -435,5 +456,12 @@ class GraphedTrainStep:
                 self.pack.buffer.copy_(host.buffer, non_blocking=True)
         for dst, src in refresh:
             dst.copy_(src, non_blocking=True)
+        if dbg:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
         self._replay()
+        if dbg:
+            torch.cuda.synchronize()
+            print("  graphed step: refresh %.2f ms, replay %.2f ms" % ((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3),
+                  flush=True)
         return self.loss
