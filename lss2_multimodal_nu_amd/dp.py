@@ -268,7 +268,7 @@ def train_step(model, bucket, opt, loss_fn, inputs, clip=5.0):
     if bucket is None:
         return train_step_local(model, opt, loss_fn, inputs, clip)
     bucket.zero()
-    ops.prepack.run()   # every registered bf16 weight image of the step in one launch (ops.WeightPrepack)
+    ops.prepack.run(bucket.params)   # every registered bf16 weight image of the step in one launch (ops.WeightPrepack)
     try:
         loss = loss_fn(model(*inputs))
         loss.backward()
@@ -310,7 +310,7 @@ def train_step_local(model, opt, loss_fn, inputs, clip=5.0):
     params = [p for g in opt.param_groups for p in g["params"]]
     for p in params:
         p.grad = None
-    ops.prepack.run()   # every registered bf16 weight image of the step in one launch (ops.WeightPrepack)
+    ops.prepack.run(params)   # every registered bf16 weight image of the step in one launch (ops.WeightPrepack)
     try:
         loss = loss_fn(model(*inputs))
         loss.backward()
@@ -389,7 +389,7 @@ class GraphedTrainStep:
                 # (thread-local capture mode: the process group's watchdog thread keeps querying its events meanwhile)
                 with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                     bucket.zero()
-                    ops.prepack.run()
+                    ops.prepack.run(bucket.params)
                     loss = loss_fn(model(*self._inputs))
                     loss.backward()
                     self.loss = loss.detach()

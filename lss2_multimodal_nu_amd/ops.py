@@ -971,8 +971,9 @@ class WeightPrepack:
     knows nothing about layouts.  A unit REGISTERS its image the first time it packs one (eager warm-up steps): the
     table comes from pushing the three byte planes of the element numbers 1..n through the unit's own pack routine
     (values <= 255 are exact in bf16), and is checked once against that routine on the real weights.  From then on
-    `run()` - called by dp.train_step* at the top of a step - fills every registered image with one launch, and the
-    units find theirs through `lookup` instead of packing; `invalidate()` after the optimizer step makes them pack
+    `run(params)` - called by dp.train_step* at the top of a step with the step's trainable tensors - fills their
+    registered images with one launch (images of tensors that are gone are dropped, not read), and the units find
+    theirs through `lookup` instead of packing; `invalidate()` after the optimizer step makes them pack
     themselves again unless another `run()` comes first, so a caller with its own loop is never handed a stale image.
     Keys are (weight address, shape, kind): whatever lives at that address is what gets packed.  LSS_PREPACK=0 disables."""
 
@@ -1019,10 +1020,18 @@ class WeightPrepack:
         self.jobs[key] = (w.data_ptr(), idx.to(torch.int32).contiguous(), dst)
         self._table = None
 
-    def run(self):
-        """Fill every registered image from the current weights (one launch per 96 images)."""
+    def run(self, params):
+        """Fill the registered images of `params` (the step's trainable tensors) from their current values: one launch
+        per 96 images.  Images registered for tensors that are not among `params` any more - a model that has been
+        deleted: its memory may be unmapped by now - are dropped, never read."""
         if not self.jobs or not self.enabled():
             return
+        live = {p.data_ptr() for p in params}
+        if any(j[0] not in live for j in self.jobs.values()):
+            self.jobs = {k: j for k, j in self.jobs.items() if j[0] in live}
+            self._table = None
+            if not self.jobs:
+                return
         if self._table is None:
             tab = (_GatherJob * len(self.jobs))()
             for i, (src, idx, dst) in enumerate(self.jobs.values()):

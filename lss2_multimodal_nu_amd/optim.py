@@ -68,7 +68,14 @@ class ClipAdam(torch.optim.Optimizer):
                 entries.append((p, g, st["exp_avg"], st["exp_avg_sq"]))
                 sizes.append(p.numel())
         n_partials = int(N.lib().lss_clip_adam_partials((ctypes.c_longlong * len(sizes))(*sizes), len(sizes)))
+        fresh_counter = device not in self._dev
         state, partials = self._device_state(device, n_partials)
+        if fresh_counter:
+            # a loaded checkpoint (this class's or torch.optim.Adam's) carries its step count per parameter: the shared
+            # device counter continues from it (read once, at the first step after the load: never inside a capture)
+            loaded = [self.state[p]["step"] for p, _, _, _ in entries if "step" in self.state[p]]
+            if loaded:
+                state[0] = float(max(float(t) for t in loaded))
         for p, _, _, _ in entries:           # 'step' of every parameter is the one shared device counter
             self.state[p]["step"] = state[0]
         # one launch group per distinct hyper-parameter set; the norm of the FIRST call covers every tensor

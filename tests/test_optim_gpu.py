@@ -87,3 +87,44 @@ def test_clip_adam_replays_in_a_graph_like_eager():
 
     a, b = run(False), run(True)
     assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
+def test_clip_adam_checkpoint_round_trip_continues_the_step_count():
+    """state_dict() -> a fresh optimizer -> load_state_dict(): the continued run equals the uninterrupted one bit for
+    bit (moments AND the bias-correction step count travel); a torch.optim.Adam checkpoint loads the same way."""
+    from lss2_multimodal_nu_amd import ClipAdam
+    p0, grads = _problem(9, 1.0)
+
+    def steps(opt, ps, gs_list):
+        for gs in gs_list:
+            for p, g in zip(ps, gs):
+                p.grad = g.clone()
+            opt.step()
+
+    pa = [torch.nn.Parameter(p.clone()) for p in p0]
+    a = ClipAdam(pa, lr=1e-2, weight_decay=1e-3, max_grad_norm=5.0)
+    steps(a, pa, grads[:5])
+    pb = [torch.nn.Parameter(p.clone()) for p in p0]
+    b = ClipAdam(pb, lr=1e-2, weight_decay=1e-3, max_grad_norm=5.0)
+    steps(b, pb, grads[:3])
+    sd = b.state_dict()
+    pc = [torch.nn.Parameter(p.detach().clone()) for p in pb]
+    c = ClipAdam(pc, lr=1e-2, weight_decay=1e-3, max_grad_norm=5.0)
+    c.load_state_dict(sd)
+    steps(c, pc, grads[3:5])
+    torch.cuda.synchronize()
+    assert all(torch.equal(u, v) for u, v in zip(pa, pc))
+    assert float(c.state_dict()["state"][0]["step"]) == 5.0
+    # a torch.optim.Adam checkpoint: same keys; the continued ClipAdam run tracks torch's own continuation
+    pt = [torch.nn.Parameter(p.clone()) for p in p0]
+    t = torch.optim.Adam(pt, lr=1e-2, weight_decay=1e-3)
+    steps(t, pt, [[g * 0.01 for g in gs] for gs in grads[:3]])
+    pd = [torch.nn.Parameter(p.detach().clone()) for p in pt]
+    d = ClipAdam(pd, lr=1e-2, weight_decay=1e-3, max_grad_norm=None)   # (torch's side of this comparison does not clip)
+    import copy
+    d.load_state_dict(copy.deepcopy(t.state_dict()))   # (load_state_dict keeps the tensors it is handed: t goes on using its own)
+    steps(t, pt, [[g * 0.01 for g in gs] for gs in grads[3:5]])
+    steps(d, pd, [[g * 0.01 for g in gs] for gs in grads[3:5]])
+    torch.cuda.synchronize()
+    worst = max(float((u - v).abs().max() / (v.abs().max() + 1e-12)) for u, v in zip(pd, pt))
+    assert worst <= 5e-6
