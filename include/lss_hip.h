@@ -405,7 +405,9 @@ int lss_bn_train_bwd_from_sums(const void* dy, const void* y, const void* z, lon
 /* One-call training units (the training step is framework-bound: chaining the launches here costs
  * two host calls per conv+BN unit instead of sixteen).
  * forward:  z = conv3x3(x) with x = x1 (up = 1, C2 = 0) or cat([x2, bilinear_align_corners(x1, up)]),
- *           y = act(BN_train(z) (+ residual));  w_packed: scratch of 9*Cout*(Cx+C2) bf16.
+ *           y = act(BN_train(z) (+ residual));  w_packed: scratch of 9*Cout*(Cx+C2) bf16 - or, with w_oihw = NULL,
+ *           the image itself, packed ahead of the step (lss_conv_bn_act_train_pack / lss_gather_pack); the same
+ *           convention for w_dgrad in the backward call.
  * backward: BN backward -> dz (and dres); if gcat != NULL: gcat = dgrad conv (B,H*up,W*up,Cx+C2) bf16
  *           (w_dgrad: scratch like w_packed), and if g1 != NULL: g1 = upsample adjoint of gcat's
  *           channels [C2, C2+Cx) -> (B,H,W,Cx); if dw != NULL: dw (Cout,Cx+C2,3,3) fp32 via
