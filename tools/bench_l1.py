@@ -68,6 +68,10 @@ def main():
                 print("   epilogue             %s" % f(q[:, 3] - q[:, 2]))
             print("   whole workgroup      %s" % f(q[:, 3] - q[:, 0]))
             print("   end after launch     %s" % f(q[:, 3] - t0))
+            if name != "K3 geometry":   # who the stragglers are: launch ids (id & 7 = XCD) of the slowest first operands
+                w = np.nonzero(sel)[0]
+                order = np.argsort(-(q[:, 1] - q[:, 0]))[:8]
+                print("   slowest first blocks: " + ", ".join("id %d (xcd %d) %.1f us" % (w[o], w[o] & 7, q[o, 1] - q[o, 0]) for o in order))
         # region splat: one workgroup per region
         q = sp[:, :4].astype(np.float64) * 0.01
         npts = sp[:, 4]
