@@ -6,6 +6,7 @@ torch's current HIP stream.  No CPU / eager fallbacks exist here.
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -979,8 +980,16 @@ class WeightPrepack:
 
     def __init__(self):
         self.jobs = {}
-        self.fresh = False
         self._table = None
+        self._tls = threading.local()   # `fresh` belongs to the thread that ran the step's `run()`
+
+    @property
+    def fresh(self):
+        return getattr(self._tls, "fresh", False)
+
+    @fresh.setter
+    def fresh(self, v):
+        self._tls.fresh = bool(v)
 
     @staticmethod
     def enabled():

@@ -83,3 +83,23 @@ def test_profile_collector_refuses_tracebacks():
                             "symbol: lss_conv2d_wgrad4x4_workspace_bytes\n", "ring_wait_stats.txt")
     assert not [f for f in os.listdir(os.path.join(root, "profiles"))
                 if "Traceback" in open(os.path.join(root, "profiles", f), errors="ignore").read()]
+
+
+def test_prepack_freshness_is_per_thread_and_stale_by_default():
+    """ops.WeightPrepack: a unit is only handed a pre-packed image between the `run()` of its own thread's step and the
+    `invalidate()` after the backward pass - never by default, never because another thread's step is in flight."""
+    import threading
+
+    from lss2_multimodal_nu_amd import ops
+    pp = ops.WeightPrepack()
+    assert pp.fresh is False and pp.lookup(__import__("torch").zeros(4), ("tile",)) is None
+    pp.fresh = True
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(pp.fresh))
+    t.start()
+    t.join()
+    assert seen == [False] and pp.fresh is True
+    pp.invalidate()
+    assert pp.fresh is False
+    pp.run([])   # nothing registered: a no-op that must not need the library
+    assert pp.fresh is False
